@@ -1,0 +1,561 @@
+/*
+ * oracle/kmpc_condensed.c -- TEST INFRASTRUCTURE (see kmpc_condensed.h).  PARITY UNPINNED.
+ */
+#include "kmpc_condensed.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+void kmpc_opts_default(kmpc_opts *o)
+{
+    o->max_iter = 200;
+    o->tol = 1e-8;
+    o->hessian = 1;
+    o->mu_init = 0.1;
+    o->bound_relax = 1e-8;
+    o->warm = 0;
+    o->warm_push = 0.01;
+    o->warm_mu = 1e-3;
+    o->max_ls = 40;
+}
+
+/* ---- "forms": the 5N-2 distinct linear forms a_f^T U behind the 10N-4 one-sided rows.
+ * f in [0,n): e_f ; [n, n+R): rate forms (R = 2(N-1)) ; [n+R, n+R+N): speed prefix sums.       */
+typedef struct {
+    int N, n, R, nf;
+    double dt;
+} forms_t;
+
+static void forms_apply(const forms_t *F, const double *x, double *y)
+{
+    const int n = F->n, N = F->N;
+    for (int j = 0; j < n; ++j) y[j] = x[j];
+    double *yr = y + n;
+    yr[0] = x[0];
+    yr[1] = x[1];
+    for (int k = 1; k <= N - 2; ++k)
+        for (int j = 0; j < 2; ++j) yr[2 * k + j] = x[2 * (k + 1) + j] - x[2 * k + j];
+    double *ys = y + n + F->R;
+    double acc = 0.0;
+    for (int k = 1; k <= N; ++k) {
+        acc += F->dt * x[2 * (k - 1)];
+        ys[k - 1] = acc;
+    }
+}
+
+static void forms_applyT_add(const forms_t *F, const double *w, double *out)
+{
+    const int n = F->n, N = F->N;
+    for (int j = 0; j < n; ++j) out[j] += w[j];
+    const double *wr = w + n;
+    out[0] += wr[0];
+    out[1] += wr[1];
+    for (int k = 1; k <= N - 2; ++k)
+        for (int j = 0; j < 2; ++j) {
+            out[2 * (k + 1) + j] += wr[2 * k + j];
+            out[2 * k + j] -= wr[2 * k + j];
+        }
+    const double *ws = w + n + F->R;
+    double suf = 0.0;
+    for (int i = N - 1; i >= 0; --i) { /* acc_i appears in v_k for k > i */
+        suf += ws[i];                  /* ws[i] is the form of v_{i+1} */
+        out[2 * i] += F->dt * suf;
+    }
+}
+
+static void forms_gram_add(const forms_t *F, const double *w, double *K)
+{
+    const int n = F->n, N = F->N;
+    for (int j = 0; j < n; ++j) K[j * n + j] += w[j];
+    const double *wr = w + n;
+    K[0] += wr[0];
+    K[n + 1] += wr[1];
+    for (int k = 1; k <= N - 2; ++k)
+        for (int j = 0; j < 2; ++j) {
+            const int a = 2 * (k + 1) + j, b = 2 * k + j;
+            const double v = wr[2 * k + j];
+            K[a * n + a] += v;
+            K[b * n + b] += v;
+            K[a * n + b] -= v;
+            K[b * n + a] -= v;
+        }
+    const double *ws = w + n + F->R;
+    /* S[i] = sum_{k>i} w(v_k) = sum_{t>=i} ws[t];  K[2i][2i'] += dt^2 S[max(i,i')] */
+    double *S = (double *)malloc((size_t)N * sizeof(double));
+    double suf = 0.0;
+    for (int i = N - 1; i >= 0; --i) {
+        suf += ws[i];
+        S[i] = suf;
+    }
+    const double dt2 = F->dt * F->dt;
+    for (int i = 0; i < N; ++i)
+        for (int i2 = 0; i2 < N; ++i2) K[(2 * i) * n + 2 * i2] += dt2 * S[i > i2 ? i : i2];
+    free(S);
+}
+
+/* per-form upper/lower right-hand sides matching kmpc_ineq()'s rows */
+static void forms_bounds(const kmpc_params *p, const kmpc_problem *q, double relax, const forms_t *F,
+                         double *bu, double *bl)
+{
+    const int n = F->n, N = F->N;
+#define RLX(x) (relax * fmax(1.0, fabs(x)))
+    for (int j = 0; j < n; ++j) {
+        const double ub = (j & 1) ? p->steer_max : p->a_max;
+        bu[j] = ub + RLX(ub);
+        bl[j] = ub + RLX(ub); /* -u_j <= -lb = ub (symmetric box) */
+    }
+    for (int j = 0; j < 2; ++j) {
+        const double d = (j ? p->steer_dmax : p->a_dmax) * p->dt_control;
+        bu[n + j] = d + RLX(d) + q->u_prev[j];
+        bl[n + j] = d + RLX(d) - q->u_prev[j];
+    }
+    for (int k = 1; k <= N - 2; ++k)
+        for (int j = 0; j < 2; ++j) {
+            const double d = (j ? p->steer_dmax : p->a_dmax) * p->dt;
+            bu[n + 2 * k + j] = d + RLX(d);
+            bl[n + 2 * k + j] = d + RLX(d);
+        }
+    for (int k = 0; k < N; ++k) {
+        bu[n + F->R + k] = p->v_max + RLX(p->v_max) - q->z0[3];
+        bl[n + F->R + k] = -p->v_min + RLX(p->v_min) + q->z0[3];
+    }
+#undef RLX
+}
+
+/* second derivatives of the Euler step wrt (psi, v, d_f), contracted with costate lam[4] -> M[3][3] */
+static void stage_hess(const kmpc_params *p, const double z[4], const double u[2], const double lam[4],
+                       double M[9])
+{
+    const double r = p->L_b / (p->L_a + p->L_b), dt = p->dt, v = z[3];
+    const double cd = cos(u[1]), sd = sin(u[1]);
+    const double D = cd * cd + r * r * sd * sd;
+    const double b1 = r / D;
+    const double b2 = r * (1.0 - r * r) * (2.0 * sd * cd) / (D * D);
+    const double beta = atan(r * tan(u[1]));
+    const double c = cos(z[2] + beta), s = sin(z[2] + beta), cb = cos(beta), sb = sin(beta);
+    const double lx = lam[0], ly = lam[1], lp = lam[2];
+    const double pp = lx * (-dt * v * c) + ly * (-dt * v * s);
+    const double pv = lx * (-dt * s) + ly * (dt * c);
+    const double pd = lx * (-dt * v * c * b1) + ly * (-dt * v * s * b1);
+    const double vd = lx * (-dt * s * b1) + ly * (dt * c * b1) + lp * (dt / p->L_b * cb * b1);
+    const double dd = lx * (-dt * v * (c * b1 * b1 + s * b2)) + ly * (dt * v * (-s * b1 * b1 + c * b2)) +
+                      lp * (dt * v / p->L_b * (-sb * b1 * b1 + cb * b2));
+    M[0] = pp; M[1] = pv; M[2] = pd;
+    M[3] = pv; M[4] = 0.; M[5] = vd;
+    M[6] = pd; M[7] = vd; M[8] = dd;
+}
+
+/* one pass: H = Gauss-Newton part (always), S = second-order part (only if S != NULL) */
+static void condense_parts(const kmpc_params *p, const kmpc_problem *q, const double *U,
+                           double *H, double *S, double *g, double *J)
+{
+    const int N = p->N, n = 2 * N;
+    const int hessian = S != NULL;
+    double *X = (double *)malloc((size_t)(N + 1) * 4 * sizeof(double));
+    double *G = (double *)calloc((size_t)4 * n, sizeof(double));
+    double *P = (double *)calloc((size_t)(N + 2) * 4, sizeof(double));
+    double A[16], B[8];
+    kmpc_rollout(p, q->z0, U, X);
+    if (J) *J = kmpc_cost(p, q, U, X);
+    memset(H, 0, (size_t)n * n * sizeof(double));
+    if (S) memset(S, 0, (size_t)n * n * sizeof(double));
+    memset(g, 0, (size_t)n * sizeof(double));
+    if (hessian == 1) { /* costates P[k] = dJ/dz_k, k = N..1 */
+        for (int k = N; k >= 1; --k) {
+            double *pk = P + 4 * k;
+            pk[0] = 2.0 * p->C[0] * (X[4 * k] - q->ref[3 * k]);
+            pk[1] = 2.0 * p->C[1] * (X[4 * k + 1] - q->ref[3 * k + 1]);
+            pk[2] = 2.0 * p->C[2] * (X[4 * k + 2] - q->ref[3 * k + 2]);
+            pk[3] = (k <= N - 1) ? 2.0 * p->C[3] * (X[4 * k + 3] - q->v_target) : 0.0;
+            if (k < N) {
+                kmpc_stage_jac(p, X + 4 * k, U + 2 * k, A, B);
+                for (int j = 0; j < 4; ++j)
+                    for (int i = 0; i < 4; ++i) pk[j] += A[4 * i + j] * P[4 * (k + 1) + i];
+            }
+        }
+    }
+    for (int k = 0; k < N; ++k) {
+        kmpc_stage_jac(p, X + 4 * k, U + 2 * k, A, B);
+        if (hessian == 1) {
+            double M[9];
+            stage_hess(p, X + 4 * k, U + 2 * k, P + 4 * (k + 1), M);
+            /* W rows: G_k[psi], G_k[v], e_{2k+1} */
+            const int nc = 2 * k + 2;
+            for (int a = 0; a < nc; ++a) {
+                const double wa[3] = {G[2 * n + a], G[3 * n + a], a == 2 * k + 1 ? 1.0 : 0.0};
+                for (int b = 0; b < nc; ++b) {
+                    const double wb[3] = {G[2 * n + b], G[3 * n + b], b == 2 * k + 1 ? 1.0 : 0.0};
+                    double s = 0.0;
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) s += wa[i] * M[3 * i + j] * wb[j];
+                    S[a * n + b] += s;
+                }
+            }
+        }
+        /* G_{k+1} = [A_k G_k | B_k] */
+        for (int c = 0; c < 2 * k; ++c) {
+            double col[4], out[4];
+            for (int i = 0; i < 4; ++i) col[i] = G[i * n + c];
+            for (int i = 0; i < 4; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < 4; ++j) s += A[4 * i + j] * col[j];
+                out[i] = s;
+            }
+            for (int i = 0; i < 4; ++i) G[i * n + c] = out[i];
+        }
+        for (int i = 0; i < 4; ++i) {
+            G[i * n + 2 * k] = B[2 * i];
+            G[i * n + 2 * k + 1] = B[2 * i + 1];
+        }
+        const int ks = k + 1, nc = 2 * ks;
+        const double Q[4] = {p->C[0], p->C[1], p->C[2], ks <= N - 1 ? p->C[3] : 0.0};
+        const double e[4] = {X[4 * ks] - q->ref[3 * ks], X[4 * ks + 1] - q->ref[3 * ks + 1],
+                             X[4 * ks + 2] - q->ref[3 * ks + 2], X[4 * ks + 3] - q->v_target};
+        for (int a = 0; a < nc; ++a) {
+            double ga = 0.0;
+            for (int i = 0; i < 4; ++i) ga += G[i * n + a] * Q[i] * e[i];
+            g[a] += 2.0 * ga;
+            for (int b = 0; b < nc; ++b) {
+                double s = 0.0;
+                for (int i = 0; i < 4; ++i) s += G[i * n + a] * Q[i] * G[i * n + b];
+                H[a * n + b] += 2.0 * s;
+            }
+        }
+    }
+    /* input terms :99-102 */
+    for (int k = 0; k < N; ++k)
+        for (int j = 0; j < 2; ++j) {
+            const int a = 2 * k + j;
+            const double Cu = p->C[6 + j], Cd = p->C[4 + j];
+            H[a * n + a] += 2.0 * Cu;
+            g[a] += 2.0 * Cu * U[a];
+            if (k + 1 < N) {
+                const int b = a + 2;
+                const double d = U[b] - U[a];
+                H[a * n + a] += 2.0 * Cd;
+                H[b * n + b] += 2.0 * Cd;
+                H[a * n + b] -= 2.0 * Cd;
+                H[b * n + a] -= 2.0 * Cd;
+                g[a] -= 2.0 * Cd * d;
+                g[b] += 2.0 * Cd * d;
+            }
+        }
+    free(X);
+    free(G);
+    free(P);
+}
+
+void kmpc_condense(const kmpc_params *p, const kmpc_problem *q, const double *U, int hessian,
+                   double *H, double *g, double *J)
+{
+    const int n = 2 * p->N;
+    if (hessian == 1) {
+        double *S = (double *)malloc((size_t)n * n * sizeof(double));
+        condense_parts(p, q, U, H, S, g, J);
+        for (int i = 0; i < n * n; ++i) H[i] += S[i];
+        free(S);
+    } else {
+        condense_parts(p, q, U, H, NULL, g, J);
+    }
+}
+
+/* in-place lower Cholesky of row-major n x n; returns 0 ok, 1 if a pivot <= tiny */
+static int chol(double *K, int n)
+{
+    for (int j = 0; j < n; ++j) {
+        double d = K[j * n + j];
+        for (int k = 0; k < j; ++k) d -= K[j * n + k] * K[j * n + k];
+        if (!(d > 0.0) || !isfinite(d)) return 1;
+        d = sqrt(d);
+        K[j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = K[i * n + j];
+            for (int k = 0; k < j; ++k) s -= K[i * n + k] * K[j * n + k];
+            K[i * n + j] = s / d;
+        }
+    }
+    return 0;
+}
+
+static void chol_solve(const double *L, int n, double *x)
+{
+    for (int i = 0; i < n; ++i) {
+        double s = x[i];
+        for (int k = 0; k < i; ++k) s -= L[i * n + k] * x[k];
+        x[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = x[i];
+        for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
+        x[i] = s / L[i * n + i];
+    }
+}
+
+/* Well-centred strictly interior point of the (relaxed) polytope; returns 0 or KMPC_INFEASIBLE.
+ * First inputs: the point of the first-step interval closest to 0, kept a quarter of the
+ * interval's width away from its ends.  Later accelerations steer v_k away from a speed bound
+ * it would otherwise sit on (the pair u_1-u_0 is rate-free, Q1); later steering angles are 0. */
+static int interior_point(const kmpc_params *p, const kmpc_problem *q, double relax, double *Uf)
+{
+    const int N = p->N;
+    memset(Uf, 0, (size_t)2 * N * sizeof(double));
+    for (int j = 0; j < 2; ++j) {
+        const double ub = j ? p->steer_max : p->a_max;
+        const double d0 = (j ? p->steer_dmax : p->a_dmax) * p->dt_control;
+        double lo = fmax(-ub - relax * fmax(1.0, ub), q->u_prev[j] - d0 - relax * fmax(1.0, d0));
+        double hi = fmin(ub + relax * fmax(1.0, ub), q->u_prev[j] + d0 + relax * fmax(1.0, d0));
+        if (j == 0) { /* v_1 = v0 + dt*acc_0 must lie inside the speed bounds */
+            lo = fmax(lo, (p->v_min - relax * fmax(1.0, fabs(p->v_min)) - q->z0[3]) / p->dt);
+            hi = fmin(hi, (p->v_max + relax * fmax(1.0, fabs(p->v_max)) - q->z0[3]) / p->dt);
+        }
+        if (!(lo < hi)) return KMPC_INFEASIBLE;
+        const double push = 0.25 * (hi - lo);
+        Uf[j] = fmin(fmax(0.0, lo + push), hi - push);
+    }
+    const double vm = fmin(1.0, 0.25 * (p->v_max - p->v_min)), gain = 1.0, acap = 0.5 * p->a_max;
+    double v = q->z0[3] + p->dt * Uf[0];
+    for (int k = 1; k < N; ++k) {
+        double a = 0.0;
+        if (v < p->v_min + vm) a = fmin(gain * (p->v_min + vm - v), acap);
+        else if (v > p->v_max - vm) a = fmax(gain * (p->v_max - vm - v), -acap);
+        Uf[2 * k] = a;
+        v += p->dt * a;
+    }
+    return 0;
+}
+
+int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc_opts *o,
+                         double *U, double *X, double *lam_out, kmpc_result *res)
+{
+    const int N = p->N, n = 2 * N;
+    forms_t F = {N, n, 2 * (N - 1), 5 * N - 2, p->dt};
+    const int nf = F.nf;
+    double *mem = (double *)calloc((size_t)(3 * n * n + 12 * n + 14 * nf + (N + 1) * 8), sizeof(double));
+    double *H = mem, *Hgn = H + n * n, *K = Hgn + n * n;
+    double *g = K + n * n, *ggn = g + n, *rhs = ggn + n, *du = rhs + n, *Ut = du + n, *Uf = Ut + n,
+           *rd = Uf + n, *tmpn = rd + n;
+    double *bu = tmpn + 5 * n, *bl = bu + nf, *su = bl + nf, *sl = su + nf, *lu = sl + nf, *ll = lu + nf,
+           *au = ll + nf, *dlu = au + nf, *dll = dlu + nf, *w = dll + nf, *aut = w + nf, *w2 = aut + nf;
+    double *Xl = w2 + 2 * nf, *Xt = Xl + (N + 1) * 4;
+    int status = KMPC_ITERATION_LIMIT, iters = 0, n_refac = 0, n_ls = 0;
+    double mu = o->warm ? o->warm_mu : o->mu_init, err0 = INFINITY, sc = 1.0, J = 0.0;
+    const double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, kappa_sigma = 1e10,
+                 eta_phi = 1e-8, s_max = 100.0;
+    const double mu_min = o->tol / 10.0;
+
+    forms_bounds(p, q, o->bound_relax, &F, bu, bl);
+    if (interior_point(p, q, o->bound_relax, Uf) != 0) {
+        status = KMPC_INFEASIBLE; /* e.g. v0 outside [v_min, v_max] (Q5) */
+        /* finite, bound-respecting command for callers that ignore status, as the reference node does */
+        for (int k = 0; k < N; ++k) {
+            U[2 * k] = fmin(fmax(q->u_prev[0], -p->a_max), p->a_max);
+            U[2 * k + 1] = fmin(fmax(q->u_prev[1], -p->steer_max), p->steer_max);
+        }
+        goto finish;
+    }
+    if (o->warm) {
+        /* U <- Uf + theta (U - Uf) with the largest theta<=1 keeping A U < b, shrunk by (1 - warm_push) */
+        for (int j = 0; j < n; ++j) du[j] = U[j] - Uf[j];
+        forms_apply(&F, Uf, au);
+        forms_apply(&F, du, aut);
+        double theta = 1.0;
+        for (int f = 0; f < nf; ++f) {
+            const double s_u = bu[f] - au[f], s_l = bl[f] + au[f];
+            if (aut[f] > 0.0) theta = fmin(theta, s_u / aut[f]);
+            if (aut[f] < 0.0) theta = fmin(theta, s_l / -aut[f]);
+        }
+        theta *= (1.0 - o->warm_push);
+        for (int j = 0; j < n; ++j) U[j] = Uf[j] + theta * du[j];
+    } else {
+        memcpy(U, Uf, (size_t)n * sizeof(double));
+    }
+    forms_apply(&F, U, au);
+    for (int f = 0; f < nf; ++f) {
+        su[f] = bu[f] - au[f];
+        sl[f] = bl[f] + au[f];
+    }
+
+    for (int it = 0; it < o->max_iter; ++it) {
+        /* linearise */
+        condense_parts(p, q, U, Hgn, o->hessian == 1 ? H : NULL, g, &J);
+        if (o->hessian == 1) for (int i = 0; i < n * n; ++i) H[i] += Hgn[i]; /* H = GN + second-order */
+        if (it == 0) {
+            /* Ipopt gradient-based scaling: nlp_scaling_max_gradient = 100 */
+            double gmax = 0.0;
+            for (int j = 0; j < n; ++j) gmax = fmax(gmax, fabs(g[j]));
+            sc = gmax > 100.0 ? 100.0 / gmax : 1.0;
+            for (int f = 0; f < nf; ++f) { lu[f] = mu / su[f]; ll[f] = mu / sl[f]; }
+        }
+        ++iters;
+        /* dual residual r_d = sc*grad J + A^T lam */
+        for (int j = 0; j < n; ++j) rd[j] = sc * g[j];
+        for (int f = 0; f < nf; ++f) w[f] = lu[f] - ll[f];
+        forms_applyT_add(&F, w, rd);
+        double rdmax = 0.0, lsum = 0.0, cmax0 = 0.0;
+        for (int j = 0; j < n; ++j) rdmax = fmax(rdmax, fabs(rd[j]));
+        for (int f = 0; f < nf; ++f) {
+            lsum += lu[f] + ll[f];
+            cmax0 = fmax(cmax0, fmax(su[f] * lu[f], sl[f] * ll[f]));
+        }
+        const double s_d = fmax(s_max, lsum / (2.0 * nf)) / s_max;
+        err0 = fmax(rdmax / s_d, cmax0 / s_d);
+        if (err0 <= o->tol) { status = KMPC_OPTIMAL; break; }
+        /* monotone barrier update (Ipopt eq. (7)) */
+        for (;;) {
+            double cmu = 0.0;
+            for (int f = 0; f < nf; ++f)
+                cmu = fmax(cmu, fmax(fabs(su[f] * lu[f] - mu), fabs(sl[f] * ll[f] - mu)));
+            const double errmu = fmax(rdmax / s_d, cmu / s_d);
+            if (errmu <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, pow(mu, theta_mu)));
+            else break;
+        }
+        const double tau = fmax(tau_min, 1.0 - mu);
+        /* K = sc*H + A^T Sigma A ; rhs = -(sc*g + A^T(mu/s_u - mu/s_l)) */
+        int use_gn = (o->hessian != 1);
+        double reg = 0.0;
+        for (int attempt = 0;; ++attempt) {
+            const double *Hs = use_gn ? Hgn : H;
+            for (int i = 0; i < n * n; ++i) K[i] = sc * Hs[i];
+            for (int f = 0; f < nf; ++f) w[f] = lu[f] / su[f] + ll[f] / sl[f];
+            forms_gram_add(&F, w, K);
+            for (int j = 0; j < n; ++j) K[j * n + j] += reg;
+            if (chol(K, n) == 0) break;
+            ++n_refac;
+            if (!use_gn) use_gn = 1;                    /* drop the second-order term first */
+            else reg = reg == 0.0 ? 1e-8 : reg * 100.0; /* then Ipopt-like delta_w escalation */
+            if (attempt > 12) { status = KMPC_NUMERICAL_ERROR; goto finish; }
+        }
+        for (int j = 0; j < n; ++j) rhs[j] = -sc * g[j];
+        for (int f = 0; f < nf; ++f) w[f] = -(mu / su[f] - mu / sl[f]);
+        forms_applyT_add(&F, w, rhs);
+        memcpy(du, rhs, (size_t)n * sizeof(double));
+        chol_solve(K, n, du);
+        forms_apply(&F, du, aut); /* a_f^T du ; ds_u = -aut, ds_l = +aut */
+        double ap = 1.0, ad = 1.0;
+        for (int f = 0; f < nf; ++f) {
+            const double dsu = -aut[f], dsl = aut[f];
+            dlu[f] = (mu - lu[f] * su[f]) / su[f] - lu[f] / su[f] * dsu;
+            dll[f] = (mu - ll[f] * sl[f]) / sl[f] - ll[f] / sl[f] * dsl;
+            if (dsu < 0.0) ap = fmin(ap, -tau * su[f] / dsu);
+            if (dsl < 0.0) ap = fmin(ap, -tau * sl[f] / dsl);
+            if (dlu[f] < 0.0) ad = fmin(ad, -tau * lu[f] / dlu[f]);
+            if (dll[f] < 0.0) ad = fmin(ad, -tau * ll[f] / dll[f]);
+        }
+        /* Armijo on phi_mu(U) = sc*J(U) - mu*sum log s  along du */
+        double phi0 = sc * J, dphi = 0.0;
+        for (int f = 0; f < nf; ++f) phi0 -= mu * (log(su[f]) + log(sl[f]));
+        for (int j = 0; j < n; ++j) dphi -= rhs[j] * du[j]; /* grad phi = -rhs */
+        double alpha = ap;
+        int accepted = 0;
+        for (int l = 0; l < o->max_ls; ++l, alpha *= 0.5) {
+            ++n_ls;
+            for (int j = 0; j < n; ++j) Ut[j] = U[j] + alpha * du[j];
+            kmpc_rollout(p, q->z0, Ut, Xt);
+            double phi = sc * kmpc_cost(p, q, Ut, Xt);
+            forms_apply(&F, Ut, w2);
+            int ok = 1;
+            for (int f = 0; f < nf; ++f) {
+                const double a = bu[f] - w2[f], b = bl[f] + w2[f];
+                if (!(a > 0.0) || !(b > 0.0)) { ok = 0; break; }
+                phi -= mu * (log(a) + log(b));
+            }
+            /* small slack for round-off as in Ipopt (10 * eps * |phi|) */
+            if (ok && phi - phi0 - 10.0 * 2.2e-16 * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = 1; break; }
+        }
+        if (!accepted) { status = KMPC_NUMERICAL_ERROR; break; }
+        if (getenv("KMPC_TRACE")) fprintf(stderr, "it %3d J %.10g err0 %.3e mu %.2e ap %.3g ad %.3g alpha %.3g rd %.3e comp %.3e gn %d\n", it, J, err0, mu, ap, ad, alpha, rdmax, cmax0, use_gn);
+        memcpy(U, Ut, (size_t)n * sizeof(double));
+        forms_apply(&F, U, au);
+        for (int f = 0; f < nf; ++f) {
+            su[f] = bu[f] - au[f];
+            sl[f] = bl[f] + au[f];
+            lu[f] += ad * dlu[f];
+            ll[f] += ad * dll[f];
+            lu[f] = fmax(fmin(lu[f], kappa_sigma * mu / su[f]), mu / (kappa_sigma * su[f]));
+            ll[f] = fmax(fmin(ll[f], kappa_sigma * mu / sl[f]), mu / (kappa_sigma * sl[f]));
+        }
+    }
+
+finish:
+    kmpc_rollout(p, q->z0, U, Xl);
+    if (X) memcpy(X, Xl, (size_t)(N + 1) * 4 * sizeof(double));
+    if (lam_out) {
+        /* kmpc_ineq row order */
+        const int R = F.R;
+        for (int j = 0; j < n; ++j) { lam_out[j] = lu[j] / sc; lam_out[n + j] = ll[j] / sc; }
+        for (int r = 0; r < R; ++r) { lam_out[2 * n + r] = lu[n + r] / sc; lam_out[2 * n + R + r] = ll[n + r] / sc; }
+        for (int k = 0; k < N; ++k) {
+            lam_out[2 * n + 2 * R + k] = lu[n + R + k] / sc;
+            lam_out[2 * n + 2 * R + N + k] = ll[n + R + k] / sc;
+        }
+    }
+    if (res) {
+        res->status = status;
+        res->iters = iters;
+        res->n_refactor = n_refac;
+        res->n_ls = n_ls;
+        res->cost = kmpc_cost(p, q, U, Xl);
+        res->viol = kmpc_max_violation(p, q, U);
+        res->kkt = err0;
+        res->mu = mu;
+    }
+    free(mem);
+    return status;
+}
+
+typedef struct {
+    const kmpc_params *p;
+    const kmpc_opts *o;
+    int b0, b1;
+    const double *z0, *ref, *vt, *up;
+    double *U, *X;
+    int *status;
+    double *cost, *viol;
+    int *iters;
+} job_t;
+
+static void *worker(void *arg)
+{
+    job_t *j = (job_t *)arg;
+    const int N = j->p->N;
+    for (int b = j->b0; b < j->b1; ++b) {
+        kmpc_problem q;
+        memcpy(q.z0, j->z0 + 4 * (size_t)b, sizeof q.z0);
+        q.ref = j->ref + (size_t)b * (N + 1) * 3;
+        q.v_target = j->vt[b];
+        q.u_prev[0] = j->up[2 * (size_t)b];
+        q.u_prev[1] = j->up[2 * (size_t)b + 1];
+        kmpc_result r;
+        kmpc_condensed_solve(j->p, &q, j->o, j->U + (size_t)b * 2 * N, j->X ? j->X + (size_t)b * (N + 1) * 4 : NULL,
+                             NULL, &r);
+        if (j->status) j->status[b] = r.status;
+        if (j->cost) j->cost[b] = r.cost;
+        if (j->viol) j->viol[b] = r.viol;
+        if (j->iters) j->iters[b] = r.iters;
+    }
+    return NULL;
+}
+
+int kmpc_condensed_solve_batch(const kmpc_params *p, const kmpc_opts *o, int B, const double *z0,
+                               const double *ref, const double *v_target, const double *u_prev, double *U,
+                               double *X, int *status, double *cost, double *viol, int *iters, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > B) nthreads = B > 0 ? B : 1;
+    pthread_t *th = (pthread_t *)malloc((size_t)nthreads * sizeof(pthread_t));
+    job_t *jobs = (job_t *)malloc((size_t)nthreads * sizeof(job_t));
+    for (int t = 0; t < nthreads; ++t) {
+        job_t j = {p, o, (int)((long long)B * t / nthreads), (int)((long long)B * (t + 1) / nthreads),
+                   z0, ref, v_target, u_prev, U, X, status, cost, viol, iters};
+        jobs[t] = j;
+        if (nthreads == 1) worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, worker, &jobs[t]);
+    }
+    if (nthreads > 1)
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+    return 0;
+}
