@@ -1,0 +1,175 @@
+"""bench.py -- MPC solves/s (batch, N=20 kinematic bicycle) on N GPUs of one node.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (kmpc_solve_batch) over one batch of synthetic (x0, path
+segment) problems already resident in HBM, followed -- for N > 1 -- by the all-gather of the
+(accel, steer) blocks.  Workload at every N: BASELINE.json configs[1], batch = 4096 problems per
+GPU, horizon 20, fp64 (weak scaling: the batch is sharded, per-GPU work is fixed).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 MFMA (v_mfma_f64_16x16x4) spec rate, SURVEY.md section 7.2
+
+
+def algorithmic_bytes_per_solve(N, es):
+    # in z0(4) + ref 3(N+1) + v_t(1) + u_prev(2); out u0(2) + int32 status
+    return (3 * N + 10) * es + 2 * es + 4
+
+
+def algorithmic_flops_per_iteration(N):
+    # linearise 150N + sensitivities 32N^2 + structured condensing sum 16k^2 + one IPM step
+    n, m = 2 * N, 10 * N - 4
+    f_cond = sum(16 * k * k for k in range(1, N + 1))
+    return 150 * N + 32 * N * N + f_cond + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
+
+
+def cpu_baseline(N, d, budget_s=15.0):
+    """oracle/ CPU port (same algorithm, scalar C, pthreads over problems) on a bounded sample."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    p = O.params(N)
+    pilot = min(4 * cores, d["z0"].shape[0])
+    t = time.perf_counter()
+    O.solve_condensed_batch(p, d["z0"][:pilot], d["ref"][:pilot], d["v_target"][:pilot], d["u_prev"][:pilot], nthreads=cores)
+    rate = pilot / max(time.perf_counter() - t, 1e-9)
+    S = int(min(d["z0"].shape[0], max(pilot, rate * budget_s)))
+    t = time.perf_counter()
+    r = O.solve_condensed_batch(p, d["z0"][:S], d["ref"][:S], d["v_target"][:S], d["u_prev"][:S], nthreads=cores)
+    el = time.perf_counter() - t
+    return dict(value=S / el, unit="solves/s", cores=cores, kind="port",
+                sample="first %d of the %d-problem GPU batch, oracle/kmpc_condensed.c (scalar fp64 C, %d pthreads), "
+                       "mean %.1f iterations" % (S, d["z0"].shape[0], cores, float(r["iters"].mean()))), r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mkz_mpc_path_follower_amd import BatchMPC
+    from mkz_mpc_path_follower_amd.dist import all_gather_solutions
+    from mkz_mpc_path_follower_amd.synthetic import make_batch
+
+    N, Bl = a.horizon, a.batch
+    tdt = torch.float64 if a.dtype == "f64" else torch.float32
+    es = 8 if a.dtype == "f64" else 4
+    B = Bl * world
+    # every rank draws its own shard of the seeded global batch (no scatter)
+    d = make_batch(Bl, N, cfg_id=2, seed=20180620 + 2 + 1000 * rank)
+    din = {k: torch.as_tensor(d[k], dtype=tdt, device=dev) for k in ("z0", "ref", "v_target", "u_prev")}
+    solver = BatchMPC(N=N, dtype=tdt, device=local)
+    out = None
+
+    def step():
+        nonlocal out
+        out = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=out)
+        return all_gather_solutions(out["u0"], B) if world > 1 else out["u0"]
+
+    for _ in range(a.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()   # same stream the kernel is launched on (torch's current stream is handed to the C ABI)
+        out = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=out)
+        ev[i][1].record()
+        if world > 1:
+            all_gather_solutions(out["u0"], B)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    iters = out["iters"].float().mean().item()
+    status = out["status"]
+    n_opt = int((status == 0).sum().item())
+
+    res = None
+    if rank == 0:
+        value = B * a.steps / el
+        flops = algorithmic_flops_per_iteration(N) * iters * Bl
+        byts = algorithmic_bytes_per_solve(N, es) * Bl
+        ach_tf = flops / (kern_ms * 1e-3) / 1e12
+        ach_gbs = byts / (kern_ms * 1e-3) / 1e9
+        res = {
+            "metric": "MPC solves/sec (batch, N=20 bicycle)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=%d problems per GPU, N=%d, %s, one wavefront per problem"
+                                   % (Bl, N, a.dtype),
+                       "batch_per_gpu": Bl, "global_batch": B, "horizon": N, "parallelism": "shard%d" % world,
+                       "mean_iterations": iters, "optimal_fraction": n_opt / Bl},
+            # the path is compute/latency-bound: fp64 VALU+MFMA roofline is the binding one
+            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "kmpc_solve_kernel", "kernel_ms": kern_ms,
+                         "flops_per_solve": algorithmic_flops_per_iteration(N) * iters},
+            "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                             "bytes_per_solve": algorithmic_bytes_per_solve(N, es)},
+        }
+        if world == 1:
+            # p50 per-solve latency: B = 1 through the same entry point, host clock around launch + sync
+            one = {k: v[:1].contiguous() for k, v in din.items()}
+            o1 = None
+            lat = []
+            for i in range(60):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                o1 = solver.solve(one["z0"], one["ref"], one["v_target"], one["u_prev"], out=o1)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t)
+            res["p50_latency_us_B1"] = float(np.percentile(lat[10:], 50) * 1e6)
+            if not a.no_cpu_baseline:
+                cb, ro = cpu_baseline(N, d)
+                res["cpu_baseline"] = cb
+                # parity spot check of the timed batch against the CPU port on the sampled problems
+                S = ro["cost"].shape[0]
+                gc = out["cost"][:S].double().cpu().numpy()
+                res["parity_sample"] = {"n": S, "max_rel_cost_err": float(np.max(np.abs(gc - ro["cost"]) / np.maximum(1.0, np.abs(ro["cost"])))),
+                                        "max_viol": float(out["viol"].max().item())}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

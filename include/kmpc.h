@@ -1,0 +1,135 @@
+/*
+ * include/kmpc.h -- C ABI of the MI355X batched kinematic-bicycle MPC solver.
+ *
+ * Drop-in boundary for ONE path of govvijaycal/mkz_mpc_path_follower: the per-step
+ * nonlinear MPC solve that scripts/mpc_cmd_pub.jl:115-141 delegates to the Julia module
+ * scripts/mpc_utils/MKZMPCPathFollower.jl (JuMP model + Ipopt).  The reference has no FFI
+ * for this path (it is an in-process Julia module with global state); the entry points
+ * below are what a binding for it would bind -- each cites the module function / global
+ * it replaces.  INTEGRATION.md shows the Julia `ccall` and Python `ctypes` stubs.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void*
+ *     (NULL = the device's default stream, exactly as in HIP; work is ordered on that stream).
+ *   - every function returns 0 on success, <0 on error (kmpc_last_error() has the text).
+ *   - the caller owns every buffer; the library keeps no pointer after a call returns
+ *     (for the async device entry point: after the stream work completes).
+ *   - one handle = one device + one stream; calls on a handle are not re-entrant.
+ *   - units as in the reference: x,y [m], psi [rad], v [m/s], acc [m/s^2], d_f [rad, tyre angle].
+ *   - input pairs are ordered (acc, d_f) = (MPC_cmd.accel_cmd, MPC_cmd.steer_angle_cmd)
+ *     (msg/MPC_cmd.msg:2-3).  NOTE the reference's update_current_input() takes them
+ *     steer-first (MKZMPCPathFollower.jl:151); the Python mirror keeps that quirk, the C ABI
+ *     does not.
+ */
+#ifndef KMPC_H
+#define KMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMPC_ABI_VERSION 1
+
+/* per-problem status, replaces the Symbol returned by solve_model() (MKZMPCPathFollower.jl:176,182) */
+enum {
+    KMPC_OPTIMAL = 0,          /* :Optimal                                   */
+    KMPC_ITERATION_LIMIT = 1,  /* :UserLimit (Ipopt max_cpu_time cap, :29)   */
+    KMPC_INFEASIBLE = 2,       /* :Infeasible (e.g. v0 outside [v_min,v_max], Q5) */
+    KMPC_NUMERICAL_ERROR = 3   /* :Error                                     */
+};
+
+enum { KMPC_F64 = 0, KMPC_F32 = 1 };
+
+/* error codes */
+enum {
+    KMPC_OK = 0,
+    KMPC_ERR_ARG = -1,      /* bad argument / unsupported configuration */
+    KMPC_ERR_HIP = -2,      /* a HIP runtime call failed */
+    KMPC_ERR_NODEVICE = -3  /* no gfx950 device / code object not loadable */
+};
+
+/* Replaces the module-level constants of MKZMPCPathFollower.jl:28-48 and the Ipopt options of :29. */
+typedef struct kmpc_config {
+    int32_t N;          /* horizon (:34, default 8); supported 2..56 */
+    int32_t dtype;      /* KMPC_F64 / KMPC_F32: arithmetic AND device-buffer element type */
+    double dt;          /* :33  0.20 */
+    double dt_control;  /* :28  0.10 */
+    double L_a, L_b;    /* :31-32 */
+    double steer_max, steer_dmax;  /* :41-42 */
+    double a_max, a_dmax;          /* :44-45 */
+    double v_min, v_max;           /* :47-48 */
+    /* solver options (Ipopt defaults where an equivalent exists) */
+    int32_t max_iter;    /* cap on linearise+factor iterations (deterministic stand-in for max_cpu_time) */
+    int32_t hessian;     /* 0 Gauss-Newton, 1 exact condensed Hessian with GN fallback */
+    double tol;          /* Ipopt tol (scaled optimality error), 1e-8 */
+    double mu_init;      /* Ipopt mu_init, 0.1 */
+    double bound_relax;  /* Ipopt bound_relax_factor, 1e-8 */
+    double warm_push;    /* weight of the interior point blended into a warm start */
+    double warm_mu;      /* mu_init used with a warm start */
+    int32_t max_ls;      /* back-tracking trial points per iteration */
+    int32_t reserved;
+} kmpc_config;
+
+typedef struct kmpc_handle kmpc_handle;
+
+int32_t kmpc_abi_version(void);
+
+/* fills the defaults of MKZMPCPathFollower.jl:28-48 for horizon N and element type dtype */
+int32_t kmpc_config_default(kmpc_config *cfg, int32_t N, int32_t dtype);
+
+/* Replaces the module load (`import MKZMPCPathFollower`, mpc_cmd_pub.jl:45-47; model build :29-123).
+ * device = HIP device ordinal.  Cost weights start at the module defaults (:51-59). */
+int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_handle **out);
+int32_t kmpc_destroy(kmpc_handle *h);
+
+/* Replaces update_cost(cx,cy,cp,cv,cda,cdd,ca,cd) (:158-169), same argument order:
+ * C_x, C_y, C_psi, C_v, C_dacc, C_ddf, C_acc, C_df. */
+int32_t kmpc_set_cost(kmpc_handle *h, const double w[8]);
+int32_t kmpc_get_cost(kmpc_handle *h, double w[8]);
+
+/* The hot path.  Replaces, for B independent problems at once,
+ *   update_init_cond (:132-138)     -> z0       [B,4]       x0,y0,psi0,v0
+ *   update_reference (:142-147)     -> ref      [B,N+1,3]   x_r,y_r,psi_r per stage (mpc_path layout
+ *                                                           xs/ys/psis interleaved; stage 0 unused, Q3)
+ *                                      v_target [B]
+ *   update_current_input (:151-154) -> u_prev   [B,2]       acc_current, d_f_current
+ *   solve_model (:173-183)          -> out_u0   [B,2]       acc_opt[1], d_f_opt[1]
+ *                                      out_status [B] int32
+ *   get_solver_results (:188-207)   -> out_U    [B,N,2]     acc_opt, d_f_opt       (optional, NULL to skip)
+ *                                      out_X    [B,N+1,4]   x,y,psi,v predictions  (optional)
+ * plus out_cost [B] (objective :97-103 at the returned inputs), out_viol [B] (max violation of
+ * the bounds :65-86, <= bound_relax when feasible), out_iters [B] int32 (optional).
+ * warm_U [B,N,2] (optional): if warm != 0 it is read as the starting inputs (JuMP re-solves from the
+ * previous primal values, Q9); it is always overwritten with the solution when non-NULL.
+ * All pointers are DEVICE pointers of the handle's dtype (status/iters int32); the call is
+ * asynchronous on `stream`.  Outputs are always written and always finite and within the input
+ * bounds, so a caller that ignores status -- as mpc_cmd_pub.jl:121-132 does -- still gets a command. */
+int32_t kmpc_solve_batch(kmpc_handle *h, int32_t B, const void *z0, const void *ref,
+                         const void *v_target, const void *u_prev, void *warm_U, int32_t warm,
+                         void *out_u0, int32_t *out_status, void *out_cost, void *out_viol,
+                         int32_t *out_iters, void *out_U, void *out_X, void *stream);
+
+/* Same with HOST pointers: copies in, solves, copies out, synchronises.  This is the form the
+ * reference's single-problem API (B = 1) maps onto. */
+int32_t kmpc_solve_batch_host(kmpc_handle *h, int32_t B, const void *z0, const void *ref,
+                              const void *v_target, const void *u_prev, void *warm_U, int32_t warm,
+                              void *out_u0, int32_t *out_status, void *out_cost, void *out_viol,
+                              int32_t *out_iters, void *out_U, void *out_X);
+
+/* text of the last error on this handle (or of the last failed kmpc_create when h == NULL) */
+const char *kmpc_last_error(kmpc_handle *h);
+
+/* ---- diagnostics used by tests/ (device pointers, handle dtype) ------------------------------ */
+/* condensed Hessian H [B,2N,2N] (full symmetric, unscaled), gradient g [B,2N], cost J [B] at U [B,N,2] */
+int32_t kmpc_debug_condense(kmpc_handle *h, int32_t B, const void *z0, const void *ref,
+                            const void *v_target, const void *U, int32_t hessian, void *H, void *g,
+                            void *J, void *stream);
+/* raw v_mfma_{f64,f32}_16x16x4 probe: a[64], b[64] lane operands -> d[64*4] lane-major results */
+int32_t kmpc_debug_mfma_probe(kmpc_handle *h, const void *a, const void *b, void *d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,263 @@
+// kmpc_api.hip -- host side of the C ABI declared in include/kmpc.h (gfx950 / MI355X only).
+// The library has no CPU fallback: every entry point that computes launches the HIP kernels
+// of kmpc_kernels.hip and fails with KMPC_ERR_NODEVICE / KMPC_ERR_HIP when it cannot.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/kmpc.h"
+#include "kmpc_device.h"
+
+template <typename T> hipError_t kmpc_launch_solve(const KP &, const KIO<T> &, hipStream_t);
+template <typename T> hipError_t kmpc_launch_condense(const KP &, const KDbg<T> &, hipStream_t);
+template <typename T> hipError_t kmpc_launch_probe(const T *, const T *, T *, hipStream_t);
+
+struct kmpc_handle {
+    kmpc_config cfg;
+    int device;
+    hipStream_t stream;
+    double cost[8];
+    std::string err;
+    // staging for the host-pointer entry point
+    void *dbuf;
+    size_t dbuf_bytes;
+};
+
+static std::string g_create_err;
+
+static int fail(kmpc_handle *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail(h, KMPC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int32_t kmpc_abi_version(void) { return KMPC_ABI_VERSION; }
+
+// MKZMPCPathFollower.jl:28-48
+extern "C" int32_t kmpc_config_default(kmpc_config *c, int32_t N, int32_t dtype)
+{
+    if (!c) return KMPC_ERR_ARG;
+    memset(c, 0, sizeof *c);
+    c->N = N;
+    c->dtype = dtype;
+    c->dt = 0.20;
+    c->dt_control = 0.10;
+    c->L_a = 1.108;
+    c->L_b = 1.742;
+    c->steer_max = 0.5;
+    c->steer_dmax = 0.5;
+    c->a_max = 1.0;
+    c->a_dmax = 1.5;
+    c->v_min = 0.0;
+    c->v_max = 20.0;
+    c->max_iter = 200;
+    c->hessian = 1;
+    c->tol = dtype == KMPC_F32 ? 1e-4 : 1e-8;
+    c->mu_init = 0.1;
+    c->bound_relax = dtype == KMPC_F32 ? 1e-5 : 1e-8;
+    c->warm_push = 0.01;
+    c->warm_mu = 1e-3;
+    c->max_ls = 30;
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: null argument");
+    if (cfg->N < 2 || cfg->N > 56) return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: horizon N=%d outside 2..56", cfg->N);
+    if (cfg->dtype != KMPC_F64 && cfg->dtype != KMPC_F32) return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: bad dtype %d", cfg->dtype);
+    if (!(cfg->dt > 0) || !(cfg->dt_control > 0) || !(cfg->L_b > 0) || !(cfg->L_a + cfg->L_b > 0) ||
+        !(cfg->v_max > cfg->v_min) || !(cfg->a_max > 0) || !(cfg->steer_max > 0) || !(cfg->steer_max < 1.5) ||
+        !(cfg->a_dmax > 0) || !(cfg->steer_dmax > 0) || cfg->max_iter < 1 || cfg->max_ls < 1 || !(cfg->tol > 0))
+        return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: invalid model / solver parameter");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_create: no HIP device");
+    if (device < 0 || device >= ndev) return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: device %d of %d", device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, KMPC_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+    kmpc_handle *h = new kmpc_handle();
+    h->cfg = *cfg;
+    h->device = device;
+    h->dbuf = nullptr;
+    h->dbuf_bytes = 0;
+    const double w0[8] = {9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0};  // :51-59
+    memcpy(h->cost, w0, sizeof w0);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(nullptr, KMPC_ERR_HIP, "kmpc_create: cannot create stream on device %d", device);
+    }
+    *out = h;
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_destroy(kmpc_handle *h)
+{
+    if (!h) return KMPC_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->dbuf) (void)hipFree(h->dbuf);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_set_cost(kmpc_handle *h, const double w[8])
+{
+    if (!h || !w) return KMPC_ERR_ARG;
+    for (int i = 0; i < 8; ++i)
+        if (!(w[i] >= 0.0)) return fail(h, KMPC_ERR_ARG, "kmpc_set_cost: weight %d is negative or NaN", i);
+    memcpy(h->cost, w, 8 * sizeof(double));
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_get_cost(kmpc_handle *h, double w[8])
+{
+    if (!h || !w) return KMPC_ERR_ARG;
+    memcpy(w, h->cost, 8 * sizeof(double));
+    return KMPC_OK;
+}
+
+extern "C" const char *kmpc_last_error(kmpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+static KP make_kp(const kmpc_handle *h, int B, int warm, int hessian_override)
+{
+    const kmpc_config &c = h->cfg;
+    KP P;
+    memset(&P, 0, sizeof P);
+    P.N = c.N; P.B = B; P.max_iter = c.max_iter;
+    P.hessian = hessian_override >= 0 ? hessian_override : c.hessian;
+    P.warm = warm; P.max_ls = c.max_ls;
+    P.dt = c.dt; P.dtc = c.dt_control; P.L_b = c.L_b; P.r = c.L_b / (c.L_a + c.L_b);
+    P.steer_max = c.steer_max; P.steer_dmax = c.steer_dmax; P.a_max = c.a_max; P.a_dmax = c.a_dmax;
+    P.v_min = c.v_min; P.v_max = c.v_max;
+    memcpy(P.C, h->cost, sizeof P.C);
+    P.tol = c.tol; P.mu_init = c.mu_init; P.relax = c.bound_relax; P.warm_push = c.warm_push; P.warm_mu = c.warm_mu;
+    P.gap_tol = c.dtype == KMPC_F32 ? 1e-4 : 1e-7;
+    return P;
+}
+
+template <typename T>
+static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, const void *vt, const void *up,
+                     void *warmU, int warm, void *u0, int32_t *status, void *cost, void *viol, int32_t *iters,
+                     void *outU, void *outX, hipStream_t st)
+{
+    KIO<T> io;
+    io.z0 = (const T *)z0; io.ref = (const T *)ref; io.vt = (const T *)vt; io.up = (const T *)up;
+    io.warmU = (T *)warmU; io.u0 = (T *)u0; io.status = status; io.cost = (T *)cost; io.viol = (T *)viol;
+    io.iters = iters; io.outU = (T *)outU; io.outX = (T *)outX;
+    const KP P = make_kp(h, B, warm && warmU ? 1 : 0, -1);
+    HIPCHK(h, kmpc_launch_solve<T>(P, io, st));
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_solve_batch(kmpc_handle *h, int32_t B, const void *z0, const void *ref, const void *v_target,
+                                    const void *u_prev, void *warm_U, int32_t warm, void *out_u0, int32_t *out_status,
+                                    void *out_cost, void *out_viol, int32_t *out_iters, void *out_U, void *out_X,
+                                    void *stream)
+{
+    if (!h) return KMPC_ERR_ARG;
+    if (B < 0) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch: B=%d", B);
+    if (B == 0) return KMPC_OK;
+    if (!z0 || !ref || !v_target || !u_prev || !out_u0 || !out_status)
+        return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch: null required buffer");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream, as in HIP
+    if (h->cfg.dtype == KMPC_F64)
+        return solve_dev<double>(h, B, z0, ref, v_target, u_prev, warm_U, warm, out_u0, out_status, out_cost, out_viol,
+                                 out_iters, out_U, out_X, st);
+    return solve_dev<float>(h, B, z0, ref, v_target, u_prev, warm_U, warm, out_u0, out_status, out_cost, out_viol,
+                            out_iters, out_U, out_X, st);
+}
+
+extern "C" int32_t kmpc_solve_batch_host(kmpc_handle *h, int32_t B, const void *z0, const void *ref,
+                                         const void *v_target, const void *u_prev, void *warm_U, int32_t warm,
+                                         void *out_u0, int32_t *out_status, void *out_cost, void *out_viol,
+                                         int32_t *out_iters, void *out_U, void *out_X)
+{
+    if (!h) return KMPC_ERR_ARG;
+    if (B < 0) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_host: B=%d", B);
+    if (B == 0) return KMPC_OK;
+    if (!z0 || !ref || !v_target || !u_prev || !out_u0 || !out_status)
+        return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_host: null required buffer");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t es = h->cfg.dtype == KMPC_F64 ? 8 : 4;
+    const size_t N = h->cfg.N, b = (size_t)B;
+    // carve one device allocation: inputs then outputs, each 256-B aligned
+    const size_t sz[13] = {b * 4 * es, b * (N + 1) * 3 * es, b * es, b * 2 * es, b * N * 2 * es,  // z0 ref vt up warmU
+                           b * 2 * es, b * 4, b * es, b * es, b * 4, b * N * 2 * es, b * (N + 1) * 4 * es, 0};
+    size_t off[13], total = 0;
+    for (int i = 0; i < 13; ++i) { off[i] = total; total += (sz[i] + 255) & ~(size_t)255; }
+    if (total > h->dbuf_bytes) {
+        if (h->dbuf) HIPCHK(h, hipFree(h->dbuf));
+        h->dbuf = nullptr; h->dbuf_bytes = 0;
+        HIPCHK(h, hipMalloc(&h->dbuf, total));
+        h->dbuf_bytes = total;
+    }
+    char *d = (char *)h->dbuf;
+    hipStream_t st = h->stream;
+    HIPCHK(h, hipMemcpyAsync(d + off[0], z0, sz[0], hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(d + off[1], ref, sz[1], hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(d + off[2], v_target, sz[2], hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(d + off[3], u_prev, sz[3], hipMemcpyHostToDevice, st));
+    if (warm_U && warm) HIPCHK(h, hipMemcpyAsync(d + off[4], warm_U, sz[4], hipMemcpyHostToDevice, st));
+    int rc = kmpc_solve_batch(h, B, d + off[0], d + off[1], d + off[2], d + off[3], warm_U ? d + off[4] : nullptr, warm,
+                              d + off[5], (int32_t *)(d + off[6]), d + off[7], d + off[8], (int32_t *)(d + off[9]),
+                              out_U ? d + off[10] : nullptr, out_X ? d + off[11] : nullptr, st);
+    if (rc != KMPC_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(out_u0, d + off[5], sz[5], hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(out_status, d + off[6], sz[6], hipMemcpyDeviceToHost, st));
+    if (out_cost) HIPCHK(h, hipMemcpyAsync(out_cost, d + off[7], sz[7], hipMemcpyDeviceToHost, st));
+    if (out_viol) HIPCHK(h, hipMemcpyAsync(out_viol, d + off[8], sz[8], hipMemcpyDeviceToHost, st));
+    if (out_iters) HIPCHK(h, hipMemcpyAsync(out_iters, d + off[9], sz[9], hipMemcpyDeviceToHost, st));
+    if (out_U) HIPCHK(h, hipMemcpyAsync(out_U, d + off[10], sz[10], hipMemcpyDeviceToHost, st));
+    if (out_X) HIPCHK(h, hipMemcpyAsync(out_X, d + off[11], sz[11], hipMemcpyDeviceToHost, st));
+    if (warm_U) HIPCHK(h, hipMemcpyAsync(warm_U, d + off[4], sz[4], hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_debug_condense(kmpc_handle *h, int32_t B, const void *z0, const void *ref, const void *v_target,
+                                       const void *U, int32_t hessian, void *H, void *g, void *J, void *stream)
+{
+    if (!h || B <= 0 || !z0 || !ref || !v_target || !U || !H || !g || !J) return h ? fail(h, KMPC_ERR_ARG, "kmpc_debug_condense: bad argument") : KMPC_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream, as in HIP
+    const KP P = make_kp(h, B, 0, hessian);
+    if (h->cfg.dtype == KMPC_F64) {
+        KDbg<double> io = {(const double *)z0, (const double *)ref, (const double *)v_target, (const double *)U,
+                           (double *)H, (double *)g, (double *)J};
+        HIPCHK(h, kmpc_launch_condense<double>(P, io, st));
+    } else {
+        KDbg<float> io = {(const float *)z0, (const float *)ref, (const float *)v_target, (const float *)U,
+                          (float *)H, (float *)g, (float *)J};
+        HIPCHK(h, kmpc_launch_condense<float>(P, io, st));
+    }
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_debug_mfma_probe(kmpc_handle *h, const void *a, const void *b, void *d, void *stream)
+{
+    if (!h || !a || !b || !d) return KMPC_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream, as in HIP
+    if (h->cfg.dtype == KMPC_F64) HIPCHK(h, kmpc_launch_probe<double>((const double *)a, (const double *)b, (double *)d, st));
+    else HIPCHK(h, kmpc_launch_probe<float>((const float *)a, (const float *)b, (float *)d, st));
+    return KMPC_OK;
+}

@@ -1,0 +1,44 @@
+// kmpc_device.h -- kernel-side parameter blocks shared by kmpc_kernels.hip and kmpc_api.hip.
+// gfx950 (MI355X) only.
+#pragma once
+#include <stdint.h>
+
+// model + solver parameters, passed to kernels by value
+struct KP {
+    int N, B, max_iter, hessian, warm, max_ls;
+    double dt, dtc, L_b, r;  // r = L_b / (L_a + L_b)  (MKZMPCPathFollower.jl:115)
+    double steer_max, steer_dmax, a_max, a_dmax, v_min, v_max;
+    double C[8];  // update_cost order: C_x, C_y, C_psi, C_v, C_dacc, C_ddf, C_acc, C_df
+    double tol, mu_init, relax, warm_push, warm_mu, gap_tol;
+};
+
+// device buffers of one batch (T = double / float)
+template <typename T>
+struct KIO {
+    const T *z0, *ref, *vt, *up;
+    T *warmU;
+    T *u0;
+    int32_t *status;
+    T *cost, *viol;
+    int32_t *iters;
+    T *outU, *outX;
+};
+
+template <typename T>
+struct KDbg {
+    const T *z0, *ref, *vt, *U;
+    T *H, *g, *J;
+};
+
+constexpr int KMPC_STG = 16;  // scalars stored per stage in LDS
+
+// LDS bytes the solver kernel needs for horizon N with NT column tiles
+template <typename T>
+inline size_t kmpc_lds_bytes(int N, int NT)
+{
+    const int n = 2 * N;
+    const int NF = (40 * NT - 2 + 63) / 64;
+    size_t elems = (size_t)n * (n + 1) + (size_t)KMPC_STG * (N + 1) + 16 * NT + 64 * NF + 64 + 16 * NT;
+    elems = (elems + 1) & ~(size_t)1;
+    return elems * sizeof(T);
+}

@@ -1,0 +1,825 @@
+// kmpc_kernels.hip -- CDNA4 (gfx950) kernels of the batched kinematic-bicycle MPC solver.
+//
+// One 64-lane wavefront solves one problem (workgroup = 1 wave, grid = batch).  The NLP is the
+// one built in the reference's scripts/mpc_utils/MKZMPCPathFollower.jl:65-123; states are
+// eliminated by forward simulation so every inequality is linear in the 2N inputs, and the
+// problem is solved by a primal-dual interior-point Newton method (Ipopt's published
+// algorithm restricted to this structure):
+//
+//   per iteration   (a) roll the bicycle model out over the horizon -- lane k owns stage k,
+//                       the recurrences v, psi, x, y are wave prefix scans (:115-122);
+//                   (b) costates by suffix scans -> exact gradient and stage Hessians;
+//                   (c) condense: stream the 4 x 2k sensitivity block G_k through the stages
+//                       and accumulate H += G_k^T P_k G_k on the matrix cores
+//                       (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, K = nx = 4);
+//                   (d) KKT matrix K = sc*H + A^T Sigma A staged in LDS, in-wave Cholesky,
+//                       two triangular solves;
+//                   (e) fraction-to-the-boundary + Armijo back-tracking on the barrier function.
+//
+// Layouts
+//   n-vector  (length n = 2N, element j = 2k + {0: acc_k, 1: d_f_k}):  lane j%64, slot j/64
+//   form-vector (the 5N-2 two-sided linear forms a_f^T U, f = lane + 64*slot):
+//        f in [0,n) box on u_f | [n, n+R) rate forms, R = 2(N-1) | [n+R, nf) speed prefix sums
+//   stage data: lane k <-> stage / state k (k = 0..N)
+//   H tiles: lower-triangular 16x16 tiles in MFMA C/D layout (col = lane&15, row from Real<T>)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "kmpc_device.h"
+
+#define DEV __device__ __forceinline__
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Real;
+template <> struct Real<double> {
+    typedef double4_t acc_t;
+    static DEV acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // C/D of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+    static DEV int row_of(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+    static DEV int q_of_row(int rr) { return rr & 3; }
+    static DEV int reg_of_row(int rr) { return rr >> 2; }
+    static DEV void sincos_(double x, double *s, double *c) { sincos(x, s, c); }
+    static DEV double eps() { return 2.220446049250313e-16; }
+    static DEV double tiny() { return 1e-300; }
+};
+template <> struct Real<float> {
+    typedef float4_t acc_t;
+    static DEV acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // C/D of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4*(lane>>4) + reg
+    static DEV int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+    static DEV int q_of_row(int rr) { return rr >> 2; }
+    static DEV int reg_of_row(int rr) { return rr & 3; }
+    static DEV void sincos_(float x, float *s, float *c) { sincosf(x, s, c); }
+    static DEV float eps() { return 1.1920929e-07f; }
+    static DEV float tiny() { return 1e-30f; }
+};
+
+// ---- wave primitives (64 lanes, one wave per workgroup) -------------------------------------
+template <typename T> DEV T wave_sum(T x) { for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o); return x; }
+template <typename T> DEV T wave_max(T x) { for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o)); return x; }
+template <typename T> DEV T wave_min(T x) { for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o)); return x; }
+template <typename T> DEV T scan_prefix(T x, int lane) {  // inclusive, lane 0 -> 63
+    for (int d = 1; d < 64; d <<= 1) { T t = __shfl_up(x, d); if (lane >= d) x += t; }
+    return x;
+}
+template <typename T> DEV T scan_suffix(T x, int lane) {  // inclusive, lane 63 -> 0
+    for (int d = 1; d < 64; d <<= 1) { T t = __shfl_down(x, d); if (lane + d < 64) x += t; }
+    return x;
+}
+#define WSYNC() __syncthreads()
+
+// per-lane stage record: lane k holds state k (k = 0..N) and input k (k < N)
+template <typename T> struct Stage {
+    T a, d, v, x, y, psi, c, s, sinb, cosb, b1, b2, ex, ey, ep, ev;
+};
+
+template <typename T, int NT> struct Solver {
+    static constexpr int NV = (16 * NT + 63) / 64;       // n-vector slots per lane
+    static constexpr int NF = (40 * NT - 2 + 63) / 64;   // form-vector slots per lane
+    static constexpr int NTT = NT * (NT + 1) / 2;        // lower-triangular tiles
+    typedef typename Real<T>::acc_t acc_t;
+
+    const KP &P;
+    const int lane, N, n, R, nf, ld;
+    T *Km, *stg, *xb, *wb, *cb, *dinv;
+    // problem data
+    T x0, y0, psi0, v0, vt, up0, up1;
+    T rx, ry, rp;  // reference at stage `lane`
+    T dt, dtc, Lb, rr_;
+    T Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
+
+    DEV Solver(const KP &p, unsigned char *smem)
+        : P(p), lane(threadIdx.x), N(p.N), n(2 * p.N), R(2 * (p.N - 1)), nf(5 * p.N - 2), ld(2 * p.N + 1)
+    {
+        Km = reinterpret_cast<T *>(smem);
+        stg = Km + n * ld;
+        xb = stg + KMPC_STG * (N + 1);
+        wb = xb + 16 * NT;
+        cb = wb + 64 * NF;
+        dinv = cb + 64;
+        dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
+        Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
+        Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
+    }
+
+    DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)
+    {
+        x0 = z0[4 * (size_t)b]; y0 = z0[4 * (size_t)b + 1]; psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
+        vt = vtp[b];
+        up0 = upp ? upp[2 * (size_t)b] : (T)0; up1 = upp ? upp[2 * (size_t)b + 1] : (T)0;
+        rx = ry = rp = (T)0;
+        if (lane <= N) {
+            const T *r = ref + ((size_t)b * (N + 1) + lane) * 3;
+            rx = r[0]; ry = r[1]; rp = r[2];
+        }
+    }
+
+    // ---- two-sided bounds of form f (relaxed like Ipopt's bound_relax_factor) -----------------
+    DEV void form_bounds(int f, T &bu, T &bl, T &rlx) const
+    {
+        const T relax = (T)P.relax;
+        if (f < n) {
+            const T ub = (f & 1) ? (T)P.steer_max : (T)P.a_max;
+            rlx = relax * fmax((T)1, ub);
+            bu = ub + rlx; bl = ub + rlx;
+        } else if (f < n + R) {
+            const int r = f - n, jj = r & 1, kk = r >> 1;
+            const T d = (jj ? (T)P.steer_dmax : (T)P.a_dmax) * (kk == 0 ? dtc : dt);
+            rlx = relax * fmax((T)1, d);
+            const T u = kk == 0 ? (jj ? up1 : up0) : (T)0;
+            bu = d + rlx + u; bl = d + rlx - u;
+        } else if (f < nf) {
+            const T ru = relax * fmax((T)1, fabs((T)P.v_max)), rl = relax * fmax((T)1, fabs((T)P.v_min));
+            bu = (T)P.v_max + ru - v0; bl = -(T)P.v_min + rl + v0;
+            rlx = fmax(ru, rl);
+        } else { bu = bl = (T)1; rlx = (T)0; }
+    }
+
+    // ---- y_f = a_f^T x ------------------------------------------------------------------------
+    DEV void forms_apply(const T (&x)[NV], T (&y)[NF])
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int j = lane + 64 * i; if (j < n) xb[j] = x[i]; }
+        WSYNC();
+        T a = lane < N ? xb[2 * lane] : (T)0;
+        a = scan_prefix(a, lane);
+        if (lane < N) cb[lane] = a;
+        WSYNC();
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = lane + 64 * i;
+            T v = (T)0;
+            if (f < n) v = xb[f];
+            else if (f < n + R) { const int r = f - n; v = r < 2 ? xb[r] : xb[r + 2] - xb[r]; }
+            else if (f < nf) v = dt * cb[f - n - R];
+            y[i] = v;
+        }
+        WSYNC();
+    }
+
+    // stage the form weights w_f in LDS (wb) together with the suffix sums of the speed weights (cb)
+    DEV void stage_form_weights(const T (&w)[NF])
+    {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; if (f < nf) wb[f] = w[i]; }
+        WSYNC();
+        T s = lane < N ? wb[n + R + lane] : (T)0;
+        s = scan_suffix(s, lane);
+        if (lane < N) cb[lane] = s;
+        WSYNC();
+    }
+    // out_j += sum_f w_f a_f[j]
+    DEV void forms_applyT_add(const T (&w)[NF], T (&out)[NV])
+    {
+        stage_form_weights(w);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int j = lane + 64 * i;
+            if (j < n) {
+                T o = wb[j];
+                if (j < 2) o += wb[n + j];
+                if (j >= 4) o += wb[n + j - 2];
+                if (j >= 2 && j < R) o -= wb[n + j];
+                if (!(j & 1)) o += dt * cb[j >> 1];
+                out[i] += o;
+            }
+        }
+        WSYNC();
+    }
+    // (A^T W A)(row, col), row >= col; needs stage_form_weights() done
+    DEV T gram_entry(int row, int col) const
+    {
+        T g = (T)0;
+        if (row == col) {
+            g = wb[row];
+            if (row < 2) g += wb[n + row];
+            if (row >= 4) g += wb[n + row - 2];
+            if (row >= 2 && row < R) g += wb[n + row];
+        } else if (row == col + 2 && col >= 2 && col < R) {
+            g = -wb[n + col];
+        }
+        if (!((row | col) & 1)) g += dt * dt * cb[row >> 1];
+        return g;
+    }
+    // Hessian of the input-cost terms (MKZMPCPathFollower.jl:99-102), row >= col
+    DEV T input_hess(int row, int col) const
+    {
+        const int jj = row & 1, k = row >> 1;
+        const T Cu = jj ? Cd : Ca, Cdl = jj ? Cdd : Cda;
+        if (row == col) return (T)2 * Cu + (T)2 * Cdl * (T)((k > 0) + (k < N - 1));
+        if (row == col + 2) return -(T)2 * Cdl;
+        return (T)0;
+    }
+
+    // ---- (a) roll-out + objective at U ----------------------------------------------------------
+    DEV T eval(const T (&U)[NV], Stage<T> &S)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int j = lane + 64 * i; if (j < n) xb[j] = U[i]; }
+        WSYNC();
+        const int k = lane;
+        const bool st = k < N;
+        T a = st ? xb[2 * k] : (T)0, d = st ? xb[2 * k + 1] : (T)0;
+        T an = (k + 1 < N) ? xb[2 * k + 2] : a, dn = (k + 1 < N) ? xb[2 * k + 3] : d;
+        WSYNC();
+        S.a = a; S.d = d;
+        const T ia = scan_prefix(a, lane);
+        const T v = v0 + dt * (ia - a);  // v_k = v0 + dt*sum_{j<k} acc_j   (:122)
+        T sd, cd;
+        Real<T>::sincos_(d, &sd, &cd);
+        const T Dn = cd * cd + rr_ * rr_ * sd * sd;
+        const T rs = (T)1 / sqrt(Dn);
+        S.sinb = rr_ * sd * rs;  // sin(atan(r tan d))   (:115)
+        S.cosb = cd * rs;
+        S.b1 = rr_ / Dn;
+        S.b2 = rr_ * ((T)1 - rr_ * rr_) * ((T)2 * sd * cd) / (Dn * Dn);
+        const T wp = st ? v * S.sinb : (T)0;
+        const T ip = scan_prefix(wp, lane);
+        const T psi = psi0 + (dt / Lb) * (ip - wp);  // (:121)
+        T sp, cp;
+        Real<T>::sincos_(psi, &sp, &cp);
+        S.c = cp * S.cosb - sp * S.sinb;  // cos(psi + beta)
+        S.s = sp * S.cosb + cp * S.sinb;
+        const T wx = st ? v * S.c : (T)0, wy = st ? v * S.s : (T)0;
+        const T ix = scan_prefix(wx, lane), iy = scan_prefix(wy, lane);
+        S.x = x0 + dt * (ix - wx);  // (:119)
+        S.y = y0 + dt * (iy - wy);  // (:120)
+        S.v = v; S.psi = psi;
+        const bool cs = (k >= 1 && k <= N);
+        S.ex = cs ? S.x - rx : (T)0;
+        S.ey = cs ? S.y - ry : (T)0;
+        S.ep = cs ? psi - rp : (T)0;
+        S.ev = (k >= 1 && k <= N - 1) ? v - vt : (T)0;
+        T Jl = Cx * S.ex * S.ex + Cy * S.ey * S.ey + Cp * S.ep * S.ep + Cv * S.ev * S.ev;  // (:97-98)
+        if (st) Jl += Ca * a * a + Cd * d * d;                                             // (:99-100)
+        if (k < N - 1) Jl += Cda * (an - a) * (an - a) + Cdd * (dn - d) * (dn - d);        // (:101-102)
+        return wave_sum(Jl);
+    }
+
+    // ---- (b) costates, gradient (n-vector g) and per-stage scalars for the condensing loop -------
+    DEV void linearize(const Stage<T> &S, bool exact, T (&g)[NV])
+    {
+        const int k = lane;
+        const bool st = k < N;
+        const T lx = (T)2 * Cx * S.ex, ly = (T)2 * Cy * S.ey, lp = (T)2 * Cp * S.ep, lv = (T)2 * Cv * S.ev;
+        const T px = scan_suffix(lx, lane), py = scan_suffix(ly, lane);
+        const T px1 = __shfl_down(px, 1), py1 = __shfl_down(py, 1);
+        const T A02 = st ? -dt * S.v * S.s : (T)0, A12 = st ? dt * S.v * S.c : (T)0;
+        const T A03 = st ? dt * S.c : (T)0, A13 = st ? dt * S.s : (T)0, A23 = st ? dt / Lb * S.sinb : (T)0;
+        const T tp = lp + (st ? A02 * px1 + A12 * py1 : (T)0);
+        const T pp = scan_suffix(tp, lane);
+        const T pp1 = __shfl_down(pp, 1);
+        const T tv = lv + (st ? A03 * px1 + A13 * py1 + A23 * pp1 : (T)0);
+        const T pv = scan_suffix(tv, lane);
+        const T pv1 = __shfl_down(pv, 1);
+        const T Bdx = st ? -dt * S.v * S.s * S.b1 : (T)0, Bdy = st ? dt * S.v * S.c * S.b1 : (T)0,
+                Bdp = st ? dt * S.v / Lb * S.cosb * S.b1 : (T)0;
+        const T aprev = __shfl_up(S.a, 1), dprev = __shfl_up(S.d, 1);
+        const T anext = __shfl_down(S.a, 1), dnext = __shfl_down(S.d, 1);
+        T ga = dt * pv1 + (T)2 * Ca * S.a, gd = Bdx * px1 + Bdy * py1 + Bdp * pp1 + (T)2 * Cd * S.d;
+        if (k >= 1) { ga += (T)2 * Cda * (S.a - aprev); gd += (T)2 * Cdd * (S.d - dprev); }
+        if (k < N - 1) { ga -= (T)2 * Cda * (anext - S.a); gd -= (T)2 * Cdd * (dnext - S.d); }
+        if (st) { xb[2 * k] = ga; xb[2 * k + 1] = gd; }
+        // second derivatives of the Euler step contracted with the costate of state k+1
+        T mpp = 0, mpv = 0, mpd = 0, mvd = 0, mdd = 0;
+        if (exact && st) {
+            const T v = S.v, c = S.c, s = S.s, b1 = S.b1, b2 = S.b2;
+            mpp = px1 * (-dt * v * c) + py1 * (-dt * v * s);
+            mpv = px1 * (-dt * s) + py1 * (dt * c);
+            mpd = px1 * (-dt * v * c * b1) + py1 * (-dt * v * s * b1);
+            mvd = px1 * (-dt * s * b1) + py1 * (dt * c * b1) + pp1 * (dt / Lb * S.cosb * b1);
+            mdd = px1 * (-dt * v * (c * b1 * b1 + s * b2)) + py1 * (dt * v * (-s * b1 * b1 + c * b2)) +
+                  pp1 * (dt * v / Lb * (-S.sinb * b1 * b1 + S.cosb * b2));
+        }
+        if (k <= N) {
+            T *q = stg + KMPC_STG * k;
+            q[0] = A02; q[1] = A03; q[2] = A12; q[3] = A13; q[4] = A23; q[5] = Bdx; q[6] = Bdy; q[7] = Bdp;
+            q[8] = mpp; q[9] = mpv; q[10] = mpd; q[11] = mvd; q[12] = mdd;
+        }
+        WSYNC();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int j = lane + 64 * i; g[i] = j < n ? xb[j] : (T)0; }
+        WSYNC();
+    }
+
+    // ---- (c) condensing on the matrix cores ------------------------------------------------------
+    // acc[tile(ti,tj)] accumulates  sum_s G_s^T (2 Q_s + M_s) G_s  + delta-row terms  (unscaled)
+    DEV void condense(bool exact, acc_t (&acc)[NTT])
+    {
+        const int kk = lane >> 4, c = lane & 15;
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        T own[NT], gps[NT], gv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) own[t] = gps[t] = gv[t] = (T)0;
+        for (int s = 0; s <= N; ++s) {
+            if (s >= 1) {  // G_s = [A_{s-1} G_{s-1} | B_{s-1}]
+                const T *q = stg + KMPC_STG * (s - 1);
+                const T A02 = q[0], A03 = q[1], A12 = q[2], A13 = q[3], A23 = q[4], Bdx = q[5], Bdy = q[6], Bdp = q[7];
+                const T cA = kk == 0 ? A02 : (kk == 1 ? A12 : (T)0);
+                const T cB = kk == 0 ? A03 : (kk == 1 ? A13 : (kk == 2 ? A23 : (T)0));
+                const T bo = kk == 0 ? Bdx : (kk == 1 ? Bdy : (kk == 2 ? Bdp : (T)0));
+                const int col0 = 2 * (s - 1);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    own[t] += cA * gps[t] + cB * gv[t];
+                    gps[t] += A23 * gv[t];
+                    const int col = 16 * t + c;
+                    if (col == col0) { own[t] = kk == 3 ? dt : (T)0; gps[t] = (T)0; gv[t] = dt; }
+                    if (col == col0 + 1) { own[t] = bo; gps[t] = Bdp; gv[t] = (T)0; }
+                }
+                const T *qs = stg + KMPC_STG * s;
+                const T mpp = (exact && s < N) ? qs[8] : (T)0, mpv = (exact && s < N) ? qs[9] : (T)0;
+                const T Cvs = s <= N - 1 ? Cv : (T)0;
+                const T dco = kk == 0 ? (T)2 * Cx : (kk == 1 ? (T)2 * Cy : (kk == 2 ? (T)2 * Cp + mpp : (T)2 * Cvs));
+                const T oco = kk >= 2 ? mpv : (T)0;
+                T bop[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bop[t] = dco * own[t] + oco * (kk == 2 ? gv[t] : gps[t]);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+                    if (16 * ti < 2 * s) {
+#pragma unroll
+                        for (int tj = 0; tj <= ti; ++tj)
+                            acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[ti * (ti + 1) / 2 + tj]);
+                    }
+            }
+            if (exact && s < N) {  // row 2s+1 (d_f of stage s) of the second-order term
+                const T *qs = stg + KMPC_STG * s;
+                const T mpd = qs[10], mvd = qs[11], mdd = qs[12];
+                const int rho = 2 * s + 1, rt = rho >> 4, rr = rho & 15;
+                const bool mine = kk == Real<T>::q_of_row(rr);
+                const int reg = Real<T>::reg_of_row(rr);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+                    if (ti == rt) {
+#pragma unroll
+                        for (int tj = 0; tj <= ti; ++tj) {
+                            T val = mpd * gps[tj] + mvd * gv[tj];
+                            if (tj == ti && c == rr) val += mdd;
+                            if (!mine) val = (T)0;
+                            acc_t &A = acc[ti * (ti + 1) / 2 + tj];
+                            A[0] += reg == 0 ? val : (T)0;
+                            A[1] += reg == 1 ? val : (T)0;
+                            A[2] += reg == 2 ? val : (T)0;
+                            A[3] += reg == 3 ? val : (T)0;
+                        }
+                    }
+            }
+        }
+    }
+
+    // ---- (d) K (lower triangle, LDS) = sc*(H + input Hessian) + A^T W A + reg*I -----------------
+    DEV void build_K(const acc_t (&acc)[NTT], T sc, T reg)
+    {
+        const int c = lane & 15;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + Real<T>::row_of(lane, r), col = 16 * tj + c;
+                    if (row < n && col <= row) {
+                        T v = sc * (acc[ti * (ti + 1) / 2 + tj][r] + input_hess(row, col)) + gram_entry(row, col);
+                        if (row == col) v += reg;
+                        Km[row * ld + col] = v;
+                    }
+                }
+        WSYNC();
+    }
+
+    // in-wave left-looking Cholesky of the lower triangle in LDS; false on a non-positive pivot
+    DEV bool cholesky()
+    {
+        for (int j = 0; j < n; ++j) {
+            T sv[NV];
+#pragma unroll
+            for (int ii = 0; ii < NV; ++ii) {
+                const int i = lane + 64 * ii;
+                T s = (T)0;
+                if (i >= j && i < n) {
+                    s = Km[i * ld + j];
+                    const T *ri = Km + i * ld, *rj = Km + j * ld;
+                    for (int k = 0; k < j; ++k) s -= ri[k] * rj[k];
+                }
+                sv[ii] = s;
+            }
+            T d = __shfl(sv[0], j & 63);
+            if (NV > 1) { const T d1 = __shfl(sv[NV - 1], j & 63); if (j >= 64) d = d1; }
+            if (!(d > Real<T>::tiny()) || !(d < (T)1e300)) return false;
+            const T dj = sqrt(d), inv = (T)1 / dj;
+#pragma unroll
+            for (int ii = 0; ii < NV; ++ii) {
+                const int i = lane + 64 * ii;
+                if (i == j) { Km[i * ld + j] = dj; dinv[j] = inv; }
+                else if (i > j && i < n) Km[i * ld + j] = sv[ii] * inv;
+            }
+            WSYNC();
+        }
+        return true;
+    }
+
+    // x <- K^{-1} x with the factor in LDS
+    DEV void chol_solve(T (&x)[NV])
+    {
+        for (int j = 0; j < n; ++j) {
+            T xj = __shfl(x[0], j & 63);
+            if (NV > 1) { const T x1 = __shfl(x[NV - 1], j & 63); if (j >= 64) xj = x1; }
+            xj *= dinv[j];
+#pragma unroll
+            for (int ii = 0; ii < NV; ++ii) {
+                const int i = lane + 64 * ii;
+                if (i == j) x[ii] = xj;
+                else if (i > j && i < n) x[ii] -= Km[i * ld + j] * xj;
+            }
+        }
+        for (int j = n - 1; j >= 0; --j) {
+            T xj = __shfl(x[0], j & 63);
+            if (NV > 1) { const T x1 = __shfl(x[NV - 1], j & 63); if (j >= 64) xj = x1; }
+            xj *= dinv[j];
+#pragma unroll
+            for (int ii = 0; ii < NV; ++ii) {
+                const int i = lane + 64 * ii;
+                if (i == j) x[ii] = xj;
+                else if (i < j) x[ii] -= Km[j * ld + i] * xj;
+            }
+        }
+    }
+
+    // well-centred strictly interior point: first inputs = point of the first-step interval closest to 0,
+    // a quarter of its width inside; later accelerations steer v_k off a speed bound (u_1-u_0 is rate-free, Q1);
+    // returns false when the first-step / speed bounds are inconsistent (Q5)
+    DEV bool interior_point(T (&Uf)[NV])
+    {
+        const T relax = (T)P.relax;
+        T u0[2];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const T ub = j ? (T)P.steer_max : (T)P.a_max;
+            const T d0 = (j ? (T)P.steer_dmax : (T)P.a_dmax) * dtc;
+            const T up = j ? up1 : up0;
+            T lo = fmax(-ub - relax * fmax((T)1, ub), up - d0 - relax * fmax((T)1, d0));
+            T hi = fmin(ub + relax * fmax((T)1, ub), up + d0 + relax * fmax((T)1, d0));
+            if (j == 0) {
+                lo = fmax(lo, ((T)P.v_min - relax * fmax((T)1, fabs((T)P.v_min)) - v0) / dt);
+                hi = fmin(hi, ((T)P.v_max + relax * fmax((T)1, fabs((T)P.v_max)) - v0) / dt);
+            }
+            if (!(lo < hi)) ok = false;
+            const T push = (T)0.25 * (hi - lo);
+            u0[j] = fmin(fmax((T)0, lo + push), hi - push);
+        }
+        const T vm = fmin((T)1, (T)0.25 * ((T)P.v_max - (T)P.v_min)), acap = (T)0.5 * (T)P.a_max;
+        T v = v0 + dt * u0[0];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) Uf[i] = (T)0;
+        if (lane == 0) Uf[0] = u0[0];
+        if (lane == 1) Uf[0] = u0[1];
+        for (int k = 1; k < N; ++k) {  // uniform scalar recurrence, N steps
+            T a = (T)0;
+            if (v < (T)P.v_min + vm) a = fmin((T)P.v_min + vm - v, acap);
+            else if (v > (T)P.v_max - vm) a = fmax((T)P.v_max - vm - v, -acap);
+            const int j = 2 * k;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (lane + 64 * i == j) Uf[i] = a;
+            v += dt * a;
+        }
+        return ok;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    DEV void solve(const KIO<T> &io, int b)
+    {
+        const T kappa_eps = 10, kappa_mu = (T)0.2, theta_mu = (T)1.5, tau_min = (T)0.99, kappa_sigma = (T)1e10,
+                eta_phi = (T)1e-8, s_max = 100;
+        const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
+        const bool exact = P.hessian == 1;
+        T U[NV], Uf[NV], g[NV], du[NV], rhs[NV], Ut[NV];
+        T bu[NF], bl[NF], rlx[NF], su[NF], sl[NF], lu[NF], ll[NF], au[NF], aut[NF], dlu[NF], dll[NF], w[NF];
+        bool fv[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i], rlx[i]); }
+        int status = 1, iters = 0;
+        T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, err0 = 0;
+        Stage<T> S, St;
+        acc_t acc[NTT];
+
+        const bool feas = interior_point(Uf);
+        if (!feas) {
+            status = 2;  // KMPC_INFEASIBLE: hold the previous command clipped into the box
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int j = lane + 64 * i;
+                const T ub = (j & 1) ? (T)P.steer_max : (T)P.a_max;
+                U[i] = j < n ? fmin(fmax((j & 1) ? up1 : up0, -ub), ub) : (T)0;
+            }
+            J = eval(U, S);
+        } else {
+            if (P.warm && io.warmU) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) { const int j = lane + 64 * i; du[i] = j < n ? io.warmU[(size_t)b * n + j] - Uf[i] : (T)0; }
+                forms_apply(Uf, au);
+                forms_apply(du, aut);
+                T th = 1;
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        const T s_u = bu[i] - au[i], s_l = bl[i] + au[i];
+                        if (aut[i] > 0) th = fmin(th, s_u / aut[i]);
+                        if (aut[i] < 0) th = fmin(th, s_l / -aut[i]);
+                    }
+                th = wave_min(th) * ((T)1 - (T)P.warm_push);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) U[i] = Uf[i] + th * du[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) U[i] = Uf[i];
+            }
+            forms_apply(U, au);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) { su[i] = bu[i] - au[i]; sl[i] = bl[i] + au[i]; }
+            J = eval(U, S);
+
+            for (int it = 0; it < P.max_iter; ++it) {
+                linearize(S, exact, g);
+                if (it == 0) {
+                    T gm = 0;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) gm = fmax(gm, fabs(g[i]));
+                    gm = wave_max(gm);
+                    sc = gm > (T)100 ? (T)100 / gm : (T)1;  // Ipopt nlp_scaling_max_gradient
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) { lu[i] = fv[i] ? mu / su[i] : (T)0; ll[i] = fv[i] ? mu / sl[i] : (T)0; }
+                }
+                ++iters;
+                // dual residual and optimality error
+#pragma unroll
+                for (int i = 0; i < NV; ++i) rhs[i] = sc * g[i];
+#pragma unroll
+                for (int i = 0; i < NF; ++i) w[i] = lu[i] - ll[i];
+                forms_applyT_add(w, rhs);
+                T rdm = 0, lsum = 0, cm0 = 0, gap = 0;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) rdm = fmax(rdm, fabs(rhs[i]));
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        lsum += lu[i] + ll[i];
+                        gap += su[i] * lu[i] + sl[i] * ll[i];
+                        cm0 = fmax(cm0, fmax(su[i] * lu[i], sl[i] * ll[i]));
+                    }
+                rdm = wave_max(rdm); lsum = wave_sum(lsum); cm0 = wave_max(cm0); gap = wave_sum(gap);
+                const T s_d = fmax(s_max, lsum / (T)(2 * nf)) / s_max;
+                err0 = fmax(rdm, cm0) / s_d;
+                // Ipopt's scaled test + an unscaled duality-gap bound: cost within gap_tol*max(1,|J|) of optimal
+                const T gap_lim = gap_tol * fmax((T)1, fabs(J));
+                if (err0 <= tol && gap / sc <= gap_lim) { status = 0; break; }
+                const T mu_min = fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf));
+                for (;;) {  // monotone barrier update
+                    T cmu = 0;
+#pragma unroll
+                    for (int i = 0; i < NF; ++i)
+                        if (fv[i]) cmu = fmax(cmu, fmax(fabs(su[i] * lu[i] - mu), fabs(sl[i] * ll[i] - mu)));
+                    cmu = wave_max(cmu);
+                    if (fmax(rdm, cmu) / s_d <= kappa_eps * mu && mu > mu_min)
+                        mu = fmax(mu_min, fmin(kappa_mu * mu, pow(mu, theta_mu)));
+                    else break;
+                }
+                const T tau = fmax(tau_min, (T)1 - mu);
+                // factor K = sc*H + A^T Sigma A
+#pragma unroll
+                for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / su[i] + ll[i] / sl[i] : (T)0;
+                bool use_exact = exact;
+                T reg = 0;
+                bool factored = false;
+                for (int attempt = 0; attempt < 14; ++attempt) {
+                    if (attempt <= 1) condense(use_exact, acc);
+                    stage_form_weights(w);
+                    build_K(acc, sc, reg);
+                    if (cholesky()) { factored = true; break; }
+                    if (use_exact) use_exact = false;            // drop the second-order term first
+                    else reg = reg == 0 ? (T)1e-8 : reg * (T)100;  // then delta_w escalation
+                }
+                if (!factored) { status = 3; break; }
+                // rhs = -(sc*g + A^T(mu/s_u - mu/s_l))
+#pragma unroll
+                for (int i = 0; i < NV; ++i) rhs[i] = -sc * g[i];
+#pragma unroll
+                for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -(mu / su[i] - mu / sl[i]) : (T)0;
+                forms_applyT_add(w, rhs);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) du[i] = rhs[i];
+                chol_solve(du);
+                forms_apply(du, aut);
+                T ap = 1, ad = 1;
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    dlu[i] = dll[i] = 0;
+                    if (fv[i]) {
+                        const T dsu = -aut[i], dsl = aut[i];
+                        dlu[i] = (mu - lu[i] * su[i]) / su[i] - lu[i] / su[i] * dsu;
+                        dll[i] = (mu - ll[i] * sl[i]) / sl[i] - ll[i] / sl[i] * dsl;
+                        if (dsu < 0) ap = fmin(ap, -tau * su[i] / dsu);
+                        if (dsl < 0) ap = fmin(ap, -tau * sl[i] / dsl);
+                        if (dlu[i] < 0) ad = fmin(ad, -tau * lu[i] / dlu[i]);
+                        if (dll[i] < 0) ad = fmin(ad, -tau * ll[i] / dll[i]);
+                    }
+                }
+                ap = wave_min(ap); ad = wave_min(ad);
+                T lg = 0, dphi = 0;
+#pragma unroll
+                for (int i = 0; i < NF; ++i) if (fv[i]) lg += log(su[i]) + log(sl[i]);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) dphi -= rhs[i] * du[i];
+                const T phi0 = sc * J - mu * wave_sum(lg);
+                dphi = wave_sum(dphi);
+                T alpha = ap, Jt = 0;
+                bool accepted = false;
+                for (int l = 0; l < P.max_ls; ++l, alpha *= (T)0.5) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Ut[i] = U[i] + alpha * du[i];
+                    Jt = eval(Ut, St);
+                    forms_apply(Ut, au);
+                    T lgt = 0;
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < NF; ++i)
+                        if (fv[i]) {
+                            const T a_ = bu[i] - au[i], b_ = bl[i] + au[i];
+                            if (!(a_ > 0) || !(b_ > 0)) ok = false; else lgt += log(a_) + log(b_);
+                        }
+                    ok = __all(ok);
+                    const T phi = sc * Jt - mu * wave_sum(lgt);
+                    if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; break; }
+                }
+                if (!accepted) { status = 3; break; }
+#pragma unroll
+                for (int i = 0; i < NV; ++i) U[i] = Ut[i];
+                S = St; J = Jt;
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        su[i] = bu[i] - au[i]; sl[i] = bl[i] + au[i];
+                        lu[i] += ad * dlu[i]; ll[i] += ad * dll[i];
+                        lu[i] = fmax(fmin(lu[i], kappa_sigma * mu / su[i]), mu / (kappa_sigma * su[i]));
+                        ll[i] = fmax(fmin(ll[i], kappa_sigma * mu / sl[i]), mu / (kappa_sigma * sl[i]));
+                    }
+            }
+        }
+        // ---- outputs ----------------------------------------------------------------------------
+        forms_apply(U, au);
+        T viol = -(T)1e30;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+            if (fv[i]) {
+                // unrelaxed bounds: b - rlx ; speed forms relax upper/lower separately
+                T ru = rlx[i], rl = rlx[i];
+                const int f = lane + 64 * i;
+                if (f >= n + R) {
+                    ru = (T)P.relax * fmax((T)1, fabs((T)P.v_max));
+                    rl = (T)P.relax * fmax((T)1, fabs((T)P.v_min));
+                }
+                viol = fmax(viol, fmax(au[i] - (bu[i] - ru), -au[i] - (bl[i] - rl)));
+            }
+        viol = wave_max(viol);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int j = lane + 64 * i;
+            if (j < n) {
+                if (io.outU) io.outU[(size_t)b * n + j] = U[i];
+                if (io.warmU) io.warmU[(size_t)b * n + j] = U[i];
+                if (j < 2) io.u0[(size_t)b * 2 + j] = U[i];
+            }
+        }
+        if (io.outX && lane <= N) {
+            T *o = io.outX + ((size_t)b * (N + 1) + lane) * 4;
+            o[0] = S.x; o[1] = S.y; o[2] = S.psi; o[3] = S.v;
+        }
+        if (lane == 0) {
+            io.status[b] = status;
+            if (io.cost) io.cost[b] = J;
+            if (io.viol) io.viol[b] = viol;
+            if (io.iters) io.iters[b] = iters;
+        }
+    }
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(64) void kmpc_solve_kernel(KP P, KIO<T> io)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    if (b >= P.B) return;
+    Solver<T, NT> sv(P, smem);
+    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
+    sv.solve(io, b);
+}
+
+// diagnostics: condensed Hessian / gradient / cost at a given U (used by the parity tests)
+template <typename T, int NT>
+__global__ __launch_bounds__(64) void kmpc_condense_kernel(KP P, KDbg<T> io)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef Solver<T, NT> SV;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= P.B) return;
+    SV sv(P, smem);
+    sv.load_problem(io.z0, io.ref, io.vt, nullptr, b);
+    const int n = 2 * P.N;
+    T U[SV::NV], g[SV::NV];
+#pragma unroll
+    for (int i = 0; i < SV::NV; ++i) { const int j = lane + 64 * i; U[i] = j < n ? io.U[(size_t)b * n + j] : (T)0; }
+    Stage<T> S;
+    const T J = sv.eval(U, S);
+    sv.linearize(S, P.hessian == 1, g);
+    typename SV::acc_t acc[SV::NTT];
+    sv.condense(P.hessian == 1, acc);
+    T *H = io.H + (size_t)b * n * n;
+    const int c = lane & 15;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + Real<T>::row_of(lane, r), col = 16 * tj + c;
+                if (row < n && col <= row) {
+                    const T v = acc[ti * (ti + 1) / 2 + tj][r] + sv.input_hess(row, col);
+                    H[row * n + col] = v;
+                    H[col * n + row] = v;
+                }
+            }
+#pragma unroll
+    for (int i = 0; i < SV::NV; ++i) { const int j = lane + 64 * i; if (j < n) io.g[(size_t)b * n + j] = g[i]; }
+    if (lane == 0) io.J[b] = J;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void kmpc_mfma_probe_kernel(const T *a, const T *b, T *d)
+{
+    const int lane = threadIdx.x;
+    typename Real<T>::acc_t acc = {0, 0, 0, 0};
+    acc = Real<T>::mfma(a[lane], b[lane], acc);
+    for (int r = 0; r < 4; ++r) d[lane * 4 + r] = acc[r];
+}
+
+// ---- launchers (called from kmpc_api.hip) ------------------------------------------------------
+template <typename T, int NT>
+static hipError_t launch_solve_nt(const KP &P, const KIO<T> &io, hipStream_t st)
+{
+    const size_t lds = kmpc_lds_bytes<T>(P.N, NT);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kmpc_solve_kernel<T, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((kmpc_solve_kernel<T, NT>), dim3(P.B), dim3(64), lds, st, P, io);
+    return hipGetLastError();
+}
+template <typename T, int NT>
+static hipError_t launch_condense_nt(const KP &P, const KDbg<T> &io, hipStream_t st)
+{
+    const size_t lds = kmpc_lds_bytes<T>(P.N, NT);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kmpc_condense_kernel<T, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((kmpc_condense_kernel<T, NT>), dim3(P.B), dim3(64), lds, st, P, io);
+    return hipGetLastError();
+}
+
+#define KMPC_DISPATCH_NT(FN, ...)                                   \
+    switch (NT) {                                                   \
+        case 1: return FN<T, 1>(__VA_ARGS__);                       \
+        case 2: return FN<T, 2>(__VA_ARGS__);                       \
+        case 3: return FN<T, 3>(__VA_ARGS__);                       \
+        case 4: return FN<T, 4>(__VA_ARGS__);                       \
+        case 5: return FN<T, 5>(__VA_ARGS__);                       \
+        case 6: return FN<T, 6>(__VA_ARGS__);                       \
+        case 7: return FN<T, 7>(__VA_ARGS__);                       \
+        default: return hipErrorInvalidValue;                       \
+    }
+
+template <typename T> hipError_t kmpc_launch_solve(const KP &P, const KIO<T> &io, hipStream_t st)
+{
+    const int NT = (2 * P.N + 15) / 16;
+    KMPC_DISPATCH_NT(launch_solve_nt, P, io, st)
+}
+template <typename T> hipError_t kmpc_launch_condense(const KP &P, const KDbg<T> &io, hipStream_t st)
+{
+    const int NT = (2 * P.N + 15) / 16;
+    KMPC_DISPATCH_NT(launch_condense_nt, P, io, st)
+}
+template <typename T> hipError_t kmpc_launch_probe(const T *a, const T *b, T *d, hipStream_t st)
+{
+    hipLaunchKernelGGL((kmpc_mfma_probe_kernel<T>), dim3(1), dim3(64), 0, st, a, b, d);
+    return hipGetLastError();
+}
+
+template hipError_t kmpc_launch_solve<double>(const KP &, const KIO<double> &, hipStream_t);
+template hipError_t kmpc_launch_solve<float>(const KP &, const KIO<float> &, hipStream_t);
+template hipError_t kmpc_launch_condense<double>(const KP &, const KDbg<double> &, hipStream_t);
+template hipError_t kmpc_launch_condense<float>(const KP &, const KDbg<float> &, hipStream_t);
+template hipError_t kmpc_launch_probe<double>(const double *, const double *, double *, hipStream_t);
+template hipError_t kmpc_launch_probe<float>(const float *, const float *, float *, hipStream_t);

@@ -1,0 +1,158 @@
+"""Batched device-side solver: thin Python host above the C ABI (include/kmpc.h).
+
+torch is used only for device memory and streams.  One BatchMPC = one handle = one GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KMPC_F32, KMPC_F64, Config
+
+DEFAULT_WEIGHTS = (9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0)  # MKZMPCPathFollower.jl:51-59
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class BatchMPC:
+    """Solves B independent kinematic-bicycle MPC problems per call on one MI355X.
+
+    Arguments mirror the reference module (scripts/mpc_utils/MKZMPCPathFollower.jl):
+    N, dt, ... are its constants (:28-48); `weights` is update_cost()'s argument list (:158-169).
+    """
+
+    def __init__(self, N=8, dtype=torch.float64, device=None, weights=None, **options):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchMPC needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.dtype = dtype
+        self.cfg = Config()
+        _lib.check(self.lib.kmpc_config_default(C.byref(self.cfg), int(N), KMPC_F64 if dtype == torch.float64 else KMPC_F32))
+        for k, v in options.items():
+            if not hasattr(self.cfg, k):
+                raise TypeError("unknown option %r" % k)
+            setattr(self.cfg, k, v)
+        self.N = int(N)
+        h = C.c_void_p()
+        _lib.check(self.lib.kmpc_create(C.byref(self.cfg), self.device.index, C.byref(h)))
+        self.h = h
+        if weights is not None:
+            self.update_cost(*weights)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kmpc_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def update_cost(self, cx, cy, cp, cv, cda, cdd, ca, cd):
+        """update_cost of MKZMPCPathFollower.jl:158-169 (same argument order)."""
+        w = (C.c_double * 8)(cx, cy, cp, cv, cda, cdd, ca, cd)
+        _lib.check(self.lib.kmpc_set_cost(self.h, w), self.h)
+
+    def _dev(self, a, shape):
+        t = torch.as_tensor(a, dtype=self.dtype, device=self.device).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+        return t
+
+    def solve(self, z0, ref, v_target, u_prev, warm_U=None, warm=False, want_U=False, want_X=False, out=None):
+        """z0[B,4], ref[B,N+1,3], v_target[B], u_prev[B,2] (acc, steer) -> dict of device tensors.
+
+        Asynchronous on torch's current stream.  `out` may carry preallocated output tensors from a
+        previous call (reused, no allocation in the timed path).
+        """
+        N = self.N
+        z0 = self._dev(z0, (len(z0), 4))
+        B = z0.shape[0]
+        ref = self._dev(ref, (B, N + 1, 3))
+        v_target = self._dev(v_target, (B,))
+        u_prev = self._dev(u_prev, (B, 2))
+        if warm_U is not None:
+            warm_U = self._dev(warm_U, (B, N, 2))
+        o = out if out is not None else {}
+        kw = dict(dtype=self.dtype, device=self.device)
+        if "u0" not in o:
+            o["u0"] = torch.empty((B, 2), **kw)
+            o["status"] = torch.empty((B,), dtype=torch.int32, device=self.device)
+            o["cost"] = torch.empty((B,), **kw)
+            o["viol"] = torch.empty((B,), **kw)
+            o["iters"] = torch.empty((B,), dtype=torch.int32, device=self.device)
+        if want_U and "U" not in o:
+            o["U"] = torch.empty((B, N, 2), **kw)
+        if want_X and "X" not in o:
+            o["X"] = torch.empty((B, N + 1, 4), **kw)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self.lib.kmpc_solve_batch(self.h, B, _ptr(z0), _ptr(ref), _ptr(v_target), _ptr(u_prev),
+                                       _ptr(warm_U), 1 if (warm and warm_U is not None) else 0,
+                                       _ptr(o["u0"]), _ptr(o["status"]), _ptr(o["cost"]), _ptr(o["viol"]),
+                                       _ptr(o["iters"]), _ptr(o.get("U") if want_U else None),
+                                       _ptr(o.get("X") if want_X else None), stream)
+        _lib.check(rc, self.h)
+        if warm_U is not None:
+            o["warm_U"] = warm_U
+        return o
+
+    # ---- diagnostics for tests ------------------------------------------------------------------
+    def debug_condense(self, z0, ref, v_target, U, hessian=1):
+        N = self.N
+        z0 = self._dev(z0, (len(z0), 4))
+        B = z0.shape[0]
+        ref = self._dev(ref, (B, N + 1, 3))
+        v_target = self._dev(v_target, (B,))
+        U = self._dev(U, (B, N, 2))
+        H = torch.zeros((B, 2 * N, 2 * N), dtype=self.dtype, device=self.device)
+        g = torch.zeros((B, 2 * N), dtype=self.dtype, device=self.device)
+        J = torch.zeros((B,), dtype=self.dtype, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib.kmpc_debug_condense(self.h, B, _ptr(z0), _ptr(ref), _ptr(v_target), _ptr(U),
+                                                int(hessian), _ptr(H), _ptr(g), _ptr(J), stream), self.h)
+        return H, g, J
+
+    def debug_mfma_probe(self, a, b):
+        a = self._dev(a, (64,))
+        b = self._dev(b, (64,))
+        d = torch.zeros((64, 4), dtype=self.dtype, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib.kmpc_debug_mfma_probe(self.h, _ptr(a), _ptr(b), _ptr(d), stream), self.h)
+        return d
+
+
+def solve_host(N, z0, ref, v_target, u_prev, weights=None, dtype=np.float64, warm_U=None, device=0, **options):
+    """Host-pointer convenience path (kmpc_solve_batch_host): numpy in, numpy out."""
+    lib = _lib.load()
+    cfg = Config()
+    _lib.check(lib.kmpc_config_default(C.byref(cfg), int(N), KMPC_F64 if dtype == np.float64 else KMPC_F32))
+    for k, v in options.items():
+        setattr(cfg, k, v)
+    h = C.c_void_p()
+    _lib.check(lib.kmpc_create(C.byref(cfg), device, C.byref(h)))
+    try:
+        if weights is not None:
+            _lib.check(lib.kmpc_set_cost(h, (C.c_double * 8)(*weights)), h)
+        z0 = np.ascontiguousarray(z0, dtype=dtype).reshape(-1, 4)
+        B = z0.shape[0]
+        ref = np.ascontiguousarray(ref, dtype=dtype).reshape(B, N + 1, 3)
+        vt = np.ascontiguousarray(v_target, dtype=dtype).reshape(B)
+        up = np.ascontiguousarray(u_prev, dtype=dtype).reshape(B, 2)
+        u0 = np.empty((B, 2), dtype)
+        st = np.empty(B, np.int32)
+        cost = np.empty(B, dtype)
+        viol = np.empty(B, dtype)
+        iters = np.empty(B, np.int32)
+        U = np.empty((B, N, 2), dtype)
+        X = np.empty((B, N + 1, 4), dtype)
+        wu = None
+        if warm_U is not None:
+            wu = np.ascontiguousarray(warm_U, dtype=dtype).reshape(B, N, 2).copy()
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        _lib.check(lib.kmpc_solve_batch_host(h, B, p(z0), p(ref), p(vt), p(up), p(wu), 1 if wu is not None else 0,
+                                             p(u0), p(st), p(cost), p(viol), p(iters), p(U), p(X)), h)
+        return dict(u0=u0, status=st, cost=cost, viol=viol, iters=iters, U=U, X=X)
+    finally:
+        lib.kmpc_destroy(h)

@@ -32,6 +32,10 @@ def make_batch(B, N, cfg_id=2, dt=0.2, hard_frac=0.05, dtype=np.float64, seed=No
     v0 = np.where(rest, 0.0, v0)
     acc_prev = np.where(rest, 0.0, acc_prev)
     e_y = np.where(far, 3.0 * sign, e_y)
+    # keep every instance feasible: the first-step rate limit (|acc_1 - acc_prev| <= 0.15) must leave
+    # room for v_2 = v0 + dt*acc_1 >= 0 (a standing car whose last command was hard braking has no
+    # feasible input in the reference NLP; that case is exercised by an explicit edge-case test)
+    acc_prev = np.maximum(acc_prev, -v0 / dt - 0.10)
 
     s = v_t[:, None] * dt * np.arange(N + 1)[None, :]
     ks = kappa[:, None] * s

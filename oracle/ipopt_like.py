@@ -220,6 +220,26 @@ class Model:
             W[id_, id_] += dd
         return W
 
+    def rollout_start(self):
+        """full-space point whose states are the roll-out (:115-122) of u_0 = previous command, u_k>0 = 0"""
+        N, dt = self.N, self.dt
+        w = np.zeros(self.nt)
+        a = np.zeros(N); d = np.zeros(N)
+        a[0] = np.clip(self.up[0], -self.a_max, self.a_max)
+        d[0] = np.clip(self.up[1], -self.steer_max, self.steer_max)
+        z = self.z0.copy()  # x, y, psi, v
+        X = [z.copy()]
+        for k in range(N):
+            b = np.arctan(self.r * np.tan(d[k]))
+            z = np.array([z[0] + dt * z[3] * np.cos(z[2] + b), z[1] + dt * z[3] * np.sin(z[2] + b),
+                          z[2] + dt * z[3] / self.L_b * np.sin(b), z[3] + dt * a[k]])
+            X.append(z.copy())
+        X = np.array(X)
+        w[self.ix:self.ix + N + 1] = X[:, 0]; w[self.iy:self.iy + N + 1] = X[:, 1]
+        w[self.ip:self.ip + N + 1] = X[:, 2]; w[self.iv:self.iv + N + 1] = X[:, 3]
+        w[self.ia:self.ia + N] = a; w[self.id:self.id + N] = d
+        return w
+
     def unpack(self, w):
         N = self.N
         X = np.stack([w[self.ix:self.ix + N + 1], w[self.iy:self.iy + N + 1],
@@ -252,7 +272,20 @@ def _inertia(Kmat):
 
 
 def solve(model, max_iter=3000, tol=1e-8, mu_init=0.1, bound_relax=1e-8, verbose=False):
-    """Ipopt-style solve of the full-space model from the reference's cold start (all primals 0)."""
+    """Ipopt-style solve of the full-space model from the reference's cold start (all primals 0, Q9).
+    Where Ipopt would enter its feasibility-restoration phase (not restated) the solve is repeated
+    from a dynamically consistent start (Model.rollout_start); the result says which start was used.
+    The KKT point reached does not depend on the start for these problems (checked against two
+    other solvers in make_golden.py)."""
+    r = _solve(model, None, max_iter, tol, mu_init, bound_relax, verbose)
+    r["start"] = "zeros"
+    if r["status"] == NUMERICAL_ERROR:
+        r = _solve(model, model.rollout_start(), max_iter, tol, mu_init, bound_relax, verbose)
+        r["start"] = "rollout"
+    return r
+
+
+def _solve(model, x_start, max_iter, tol, mu_init, bound_relax, verbose):
     m = model
     nt, nc = m.nt, m.nc
     xL, xU = m.bounds()
@@ -261,7 +294,7 @@ def solve(model, max_iter=3000, tol=1e-8, mu_init=0.1, bound_relax=1e-8, verbose
     xL = np.where(hasL, xL - bound_relax * np.maximum(1.0, np.abs(xL)), xL)
     xU = np.where(hasU, xU + bound_relax * np.maximum(1.0, np.abs(xU)), xU)
     # starting point: JuMP start=0.0 for every variable; slacks start at d(x0)
-    x = np.zeros(nt)
+    x = np.zeros(nt) if x_start is None else np.array(x_start, float)
     x[m.nv:] = m.rate_expr(x)
     k1 = k2 = 1e-2
     both = hasL & hasU

@@ -343,7 +343,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc
     double mu = o->warm ? o->warm_mu : o->mu_init, err0 = INFINITY, sc = 1.0, J = 0.0;
     const double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, kappa_sigma = 1e10,
                  eta_phi = 1e-8, s_max = 100.0;
-    const double mu_min = o->tol / 10.0;
+    const double gap_tol = 1e-7;
 
     forms_bounds(p, q, o->bound_relax, &F, bu, bl);
     if (interior_point(p, q, o->bound_relax, Uf) != 0) {
@@ -393,15 +393,20 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc
         for (int j = 0; j < n; ++j) rd[j] = sc * g[j];
         for (int f = 0; f < nf; ++f) w[f] = lu[f] - ll[f];
         forms_applyT_add(&F, w, rd);
-        double rdmax = 0.0, lsum = 0.0, cmax0 = 0.0;
+        double rdmax = 0.0, lsum = 0.0, cmax0 = 0.0, gap = 0.0;
         for (int j = 0; j < n; ++j) rdmax = fmax(rdmax, fabs(rd[j]));
         for (int f = 0; f < nf; ++f) {
             lsum += lu[f] + ll[f];
+            gap += su[f] * lu[f] + sl[f] * ll[f];
             cmax0 = fmax(cmax0, fmax(su[f] * lu[f], sl[f] * ll[f]));
         }
         const double s_d = fmax(s_max, lsum / (2.0 * nf)) / s_max;
         err0 = fmax(rdmax / s_d, cmax0 / s_d);
-        if (err0 <= o->tol) { status = KMPC_OPTIMAL; break; }
+        /* Ipopt's scaled test, plus an UNSCALED duality-gap bound so that the cost is within
+           gap_tol*max(1,|J|) of the optimum whatever the objective scaling was */
+        const double gap_lim = gap_tol * fmax(1.0, fabs(J));
+        if (err0 <= o->tol && gap / sc <= gap_lim) { status = KMPC_OPTIMAL; break; }
+        const double mu_min = fmin(o->tol / 10.0, 0.1 * gap_lim * sc / (2.0 * nf));
         /* monotone barrier update (Ipopt eq. (7)) */
         for (;;) {
             double cmu = 0.0;

@@ -1,0 +1,98 @@
+"""oracle/make_golden.py -- TEST INFRASTRUCTURE.  Generates tests/golden/*.npz.
+
+The reference (Julia/JuMP/Ipopt) cannot run here and ships no golden vectors, so these fixtures
+are NOT reference outputs: PARITY UNPINNED.  Each fixture problem is solved by three independent
+solvers and stored only if they agree:
+  (1) oracle/ipopt_like.py     full-space restatement of the JuMP model + Ipopt's published algorithm
+  (2) oracle/kmpc_condensed.c  state-eliminated Newton / interior-point (the algorithm the HIP kernels run)
+  (3) scipy.optimize.minimize(method="trust-constr") on the state-eliminated problem with the
+      analytic gradient / Hessian of oracle/kmpc_nlp.c and the linear inequalities of kmpc_ineq()
+Run from the repo root:  python oracle/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+from scipy.optimize import LinearConstraint, minimize
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ipopt_like as IL  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from mkz_mpc_path_follower_amd.synthetic import make_batch  # noqa: E402
+
+NODE_WEIGHTS = (9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0)  # mpc_cmd_pub.jl:49
+
+
+def kat_problems(N, dt=0.2):
+    """SURVEY.md section 7.3 known-answer cases."""
+    k = np.arange(N + 1)
+    line = np.zeros((N + 1, 3))
+    line[:, 0] = 15.0 * dt * k  # MKZMPCPathFollower.jl:36-39
+    # circle R = 40 m at 10 m/s
+    s = 10.0 * dt * k
+    circ = np.stack([40.0 * np.sin(s / 40.0), 40.0 * (1 - np.cos(s / 40.0)), s / 40.0], axis=1)
+    P = [
+        dict(name="on_path_at_speed", z0=[0, 0, 0, 15.0], ref=line, vt=15.0, up=[0, 0]),
+        dict(name="module_load_standing_start", z0=[0, 0, 0, 0.0], ref=line, vt=15.0, up=[0, 0]),
+        dict(name="offset_1m_0.1rad", z0=[0, 1.0, 0.1, 10.0], ref=line, vt=15.0, up=[0, 0]),
+        dict(name="circle_R40", z0=[0, 0.5, -0.05, 9.0], ref=circ, vt=10.0, up=[0, 0]),
+        dict(name="mirror_offset", z0=[0, -1.0, -0.1, 10.0], ref=line * np.array([1, -1, -1]), vt=15.0, up=[0, 0]),
+        dict(name="nonzero_prev_input", z0=[0, 0.3, 0.02, 8.0], ref=circ, vt=10.0, up=[0.4, 0.07]),
+    ]
+    return P
+
+
+def scipy_solve(p, q, U0):
+    A, b = O.ineq(p, q, relax=1e-8)
+    n = 2 * p.N
+    fun = lambda u: O.cost(p, q, u)
+    jac = lambda u: O.grad(p, q, u)
+    hess = lambda u: O.condense(p, q, u, hessian=1)[0]
+    res = minimize(fun, U0.ravel(), jac=jac, hess=hess, method="trust-constr",
+                   constraints=[LinearConstraint(A, -np.inf, b)],
+                   options=dict(gtol=1e-10, xtol=1e-14, barrier_tol=1e-12, maxiter=3000, initial_barrier_parameter=0.1))
+    return res.x.reshape(p.N, 2), res.fun
+
+
+def build(N, n_random, cfg_id):
+    p = O.params(N, NODE_WEIGHTS)
+    probs = kat_problems(N)
+    d = make_batch(n_random, N, cfg_id=cfg_id)
+    for i in range(n_random):
+        probs.append(dict(name="synthetic_%d%s" % (i, "_hard" if d["hard"][i] else ""), z0=d["z0"][i], ref=d["ref"][i],
+                          vt=d["v_target"][i], up=d["u_prev"][i]))
+    rows = []
+    for pr in probs:
+        q = O.problem(p, pr["z0"], pr["ref"], pr["vt"], pr["up"])
+        rc = O.solve_condensed(p, q)
+        ri = IL.solve_problem(N, pr["z0"], pr["ref"], pr["vt"], pr["up"], weights=NODE_WEIGHTS)
+        assert rc["status"] == 0, pr["name"]
+        assert ri["status"] == 0, (pr["name"], ri)
+        Us, Js = scipy_solve(p, q, rc["U"] * 0.5)
+        Jc, Ji = rc["cost"], ri["cost"]
+        scale = max(1.0, abs(Ji))
+        cert = O.certify(p, q, rc["U"], rc["lam"])
+        agree = max(abs(Jc - Ji), abs(Js - Ji)) / scale
+        print("N=%2d %-28s J ipopt-like %.10g condensed %.10g scipy %.10g | rel spread %.1e | dU(c,i) %.1e dU(s,i) %.1e | KKT %.1e viol %.1e"
+              % (N, pr["name"], Ji, Jc, Js, agree, np.abs(rc["U"] - ri["U"]).max(), np.abs(Us - ri["U"]).max(),
+                 cert["stationarity"], cert["violation"]))
+        assert agree < 2e-7, pr["name"]
+        rows.append(dict(pr=pr, Ji=Ji, Jc=Jc, Js=Js, Ui=ri["U"], Uc=rc["U"], Us=Us, Xi=ri["X"]))
+    out = dict(
+        N=np.int32(N), weights=np.array(NODE_WEIGHTS), names=np.array([r["pr"]["name"] for r in rows]),
+        z0=np.array([r["pr"]["z0"] for r in rows], float), ref=np.array([r["pr"]["ref"] for r in rows], float),
+        v_target=np.array([r["pr"]["vt"] for r in rows], float), u_prev=np.array([r["pr"]["up"] for r in rows], float),
+        J_ipopt_like=np.array([r["Ji"] for r in rows]), J_condensed=np.array([r["Jc"] for r in rows]),
+        J_scipy=np.array([r["Js"] for r in rows]), U_ipopt_like=np.array([r["Ui"] for r in rows]),
+        U_condensed=np.array([r["Uc"] for r in rows]), U_scipy=np.array([r["Us"] for r in rows]),
+        X_ipopt_like=np.array([r["Xi"] for r in rows]))
+    path = os.path.join(ROOT, "tests", "golden", "kmpc_N%d.npz" % N)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    build(8, 26, cfg_id=101)
+    build(20, 18, cfg_id=102)
+    build(50, 4, cfg_id=105)

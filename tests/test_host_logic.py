@@ -1,0 +1,119 @@
+"""Host-side logic that needs no GPU: synthetic batches, sharding, the control-loop mirror of
+scripts/mpc_cmd_pub.jl (with a stand-in MPC object), and the N>1 all-gather on gloo (world_size 2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mkz_mpc_path_follower_amd.dist import all_gather_solutions, shard_range
+from mkz_mpc_path_follower_amd.messages import MPCCmd, MPCPath, StateEst
+from mkz_mpc_path_follower_amd.node import MPCNode
+from mkz_mpc_path_follower_amd.synthetic import make_batch, straight_line_case
+
+
+def test_synthetic_batch_is_seeded_and_feasible(oracle):
+    a, b = make_batch(256, 20, cfg_id=2), make_batch(256, 20, cfg_id=2)
+    for k in ("z0", "ref", "v_target", "u_prev"):
+        assert np.array_equal(a[k], b[k])
+    assert a["z0"].shape == (256, 4) and a["ref"].shape == (256, 21, 3) and a["u_prev"].shape == (256, 2)
+    assert (a["z0"][:, 3] >= 0).all() and (a["z0"][:, 3] <= 20).all()
+    # reference spacing = v_target * dt (ref_gps_traj.py:175)
+    ds = np.linalg.norm(np.diff(a["ref"][:, :, :2], axis=1), axis=2)
+    assert np.allclose(ds, a["v_target"][:, None] * 0.2, rtol=2e-3)
+    r = oracle.solve_condensed_batch(oracle.params(20), a["z0"][:64], a["ref"][:64], a["v_target"][:64], a["u_prev"][:64], nthreads=8)
+    assert (r["status"] == 0).all()
+    s = straight_line_case(8)
+    assert np.allclose(s["ref"][0, :, 0], 15.0 * 0.2 * np.arange(9))  # MKZMPCPathFollower.jl:36-37
+
+
+def test_shard_ranges_cover_the_batch():
+    for B in (1, 7, 4096, 2097152):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(B, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == B
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class FakeMPC:
+    """records the call protocol of mpc_cmd_pub.jl:115-141"""
+
+    def __init__(self, N=8):
+        self.N, self.calls = N, []
+
+    def update_cost(self, *w): self.calls.append(("update_cost", w))
+    def update_init_cond(self, *a): self.calls.append(("update_init_cond", a))
+    def update_reference(self, x, y, p, v): self.calls.append(("update_reference", (len(x), len(y), len(p), v)))
+    def update_current_input(self, swa, acc): self.calls.append(("update_current_input", (swa, acc)))
+    def solve_model(self): self.calls.append(("solve_model", ())); return 0.12, -0.03, "Optimal"
+
+    def get_solver_results(self):
+        n = self.N + 1
+        z = np.zeros(n)
+        return (z + 1, z + 2, z + 3, z + 4, z, z, z, np.zeros(self.N), np.zeros(self.N))
+
+
+def test_node_loop_protocol_and_stop_latch():
+    pub = []
+    stop = {"v": False}
+
+    def wp(x, y, psi, v=None):
+        n = 9
+        return np.arange(n) + x, np.zeros(n) + y, np.zeros(n) + psi, stop["v"]
+
+    mpc = FakeMPC()
+    node = MPCNode(wp, lambda t, m: pub.append((t, m)), target_vel=5.0, mpc=mpc)
+    assert pub[0][0] == "enable"                                         # mpc_cmd_pub.jl:172
+    assert mpc.calls[0] == ("update_cost", (9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0))  # :49
+    assert node.step() is None                                           # nothing until a state arrives (:88-91)
+    node.state_est_callback(StateEst(x=1.0, y=2.0, psi=0.3, v=4.0))
+    cmd = node.step()
+    assert isinstance(cmd, MPCCmd) and (cmd.accel_cmd, cmd.steer_angle_cmd) == (0.12, -0.03)
+    names = [c[0] for c in mpc.calls[1:]]
+    assert names == ["update_init_cond", "update_reference", "solve_model", "update_current_input"]
+    assert mpc.calls[1][1] == (1.0, 2.0, 0.3, 4.0)
+    assert mpc.calls[2][1] == (9, 9, 9, 5.0)
+    assert mpc.calls[4][1] == (-0.03, 0.12)                              # steer first (Q6, :140)
+    topics = [t for t, _ in pub[1:]]
+    assert topics == ["mpc_cmd", "target_path", "mpc_path"]
+    path = pub[-1][1]
+    assert isinstance(path, MPCPath) and path.xs[0] == 1 and path.ys[0] == 2 and path.psis[0] == 4  # res[1], res[2], res[4]
+    stop["v"] = True                                                     # stop latch (:102-104, :148-153)
+    cmd = node.step()
+    assert (cmd.accel_cmd, cmd.steer_angle_cmd) == (-1.0, 0.0)
+    stop["v"] = False
+    n_solves = sum(1 for c in mpc.calls if c[0] == "solve_model")
+    cmd = node.step()
+    assert (cmd.accel_cmd, cmd.steer_angle_cmd) == (-1.0, 0.0)           # latched forever
+    assert sum(1 for c in mpc.calls if c[0] == "solve_model") == n_solves
+
+
+def _gather_worker(rank, world, port, B, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(B, rank, world)
+    full = torch.arange(B * 2, dtype=torch.float64).reshape(B, 2)
+    got = all_gather_solutions(full[lo:hi].clone(), B)
+    q.put((rank, bool(torch.equal(got, full))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [8, 7])
+def test_all_gather_of_solution_shards_gloo_world2(B):
+    """N>1 path: contiguous shards, one all-gather of the [B/G, 2] (accel, steer) blocks (even and ragged)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + B) % 2000
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,181 @@
+"""CPU tests of the oracle (oracle/): known answers, quirks of the reference NLP, derivative checks,
+agreement with the committed golden fixtures.  The reference has no tests of its own."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NODE_W = (9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0)
+
+
+def line_ref(N, v=15.0, dt=0.2):
+    r = np.zeros((N + 1, 3))
+    r[:, 0] = v * dt * np.arange(N + 1)
+    return r
+
+
+@pytest.mark.parametrize("N", [8, 20, 50])
+def test_on_path_at_speed_is_zero(oracle, N):
+    O = oracle
+    p = O.params(N)
+    r = O.solve_condensed(p, O.problem(p, [0, 0, 0, 15.0], line_ref(N), 15.0))
+    assert r["status"] == 0 and abs(r["cost"]) < 1e-12 and np.abs(r["U"]).max() < 1e-7
+
+
+@pytest.mark.parametrize("N,J", [(8, 15738.467), (20, 194745.62), (50, 2050558.8)])
+def test_module_load_problem(oracle, N, J):
+    """BASELINE config 1 (MKZMPCPathFollower.jl:36-39,110-113,127): standing start, straight reference.
+    Pure QP in acc; first-step rate bound a_dmax*dt_control = 0.15 is active (Q2)."""
+    O = oracle
+    p = O.params(N)
+    r = O.solve_condensed(p, O.problem(p, [0, 0, 0, 0.0], line_ref(N), 15.0))
+    assert r["status"] == 0
+    assert abs(r["cost"] - J) < 1e-7 * J
+    assert abs(r["U"][0, 0] - 0.15) < 2e-8 and np.abs(r["U"][:, 1]).max() < 1e-9
+    # Q1: the pair u_2 - u_1 is NOT rate constrained -> the optimum jumps by more than a_dmax*dt = 0.3
+    assert r["U"][1, 0] - r["U"][0, 0] > 0.3 + 1e-3
+    # later pairs are constrained
+    assert np.all(np.abs(np.diff(r["U"][1:, 0])) <= 0.3 + 1e-7)
+
+
+def test_first_step_bounds_active(oracle):
+    O = oracle
+    p = O.params(8)
+    r = O.solve_condensed(p, O.problem(p, [0, 1.0, 0.1, 10.0], line_ref(8), 15.0))
+    assert abs(r["U"][0, 0] - 0.15) < 2e-8 and abs(r["U"][0, 1] + 0.05) < 2e-8
+    assert abs(r["cost"] - 1692.89097) < 1e-4
+
+
+def test_mirror_and_rigid_motion_invariance(oracle):
+    """mirroring y/psi flips d_f; rotation + translation leave U*, J* unchanged (C_x = C_y)."""
+    O = oracle
+    N = 8
+    p = O.params(N, NODE_W)
+    ref = line_ref(N, 10.0)
+    z0 = np.array([0.0, 0.8, 0.05, 9.0])
+    r0 = O.solve_condensed(p, O.problem(p, z0, ref, 10.0, (0.1, 0.02)))
+    m = np.array([1.0, -1.0, -1.0])
+    r1 = O.solve_condensed(p, O.problem(p, z0 * np.array([1, -1, -1, 1]), ref * m, 10.0, (0.1, -0.02)))
+    assert abs(r0["cost"] - r1["cost"]) < 1e-7 * r0["cost"]
+    assert np.abs(r0["U"][:, 0] - r1["U"][:, 0]).max() < 1e-5 and np.abs(r0["U"][:, 1] + r1["U"][:, 1]).max() < 1e-5
+    th, t = 0.7, np.array([3.0, -2.0])
+    Rm = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    ref2 = ref.copy()
+    ref2[:, :2] = ref[:, :2] @ Rm.T + t
+    ref2[:, 2] += th
+    z2 = z0.copy()
+    z2[:2] = Rm @ z0[:2] + t
+    z2[2] += th
+    r2 = O.solve_condensed(p, O.problem(p, z2, ref2, 10.0, (0.1, 0.02)))
+    assert abs(r0["cost"] - r2["cost"]) < 1e-7 * r0["cost"]
+    assert np.abs(r0["U"] - r2["U"]).max() < 1e-5
+
+
+def test_quirks_dead_inputs(oracle):
+    """Q3: x_r[1], y_r[1], psi_r[1] are dead inputs; terminal v is not in the C_v term."""
+    O = oracle
+    N = 8
+    w = list(NODE_W)
+    w[3] = 5.0  # C_v > 0 so the speed term matters
+    p = O.params(N, w)
+    ref = line_ref(N, 10.0)
+    q = O.problem(p, [0, 0.2, 0, 8.0], ref, 10.0)
+    r0 = O.solve_condensed(p, q)
+    ref2 = ref.copy()
+    ref2[0] = [123.0, -45.0, 2.0]
+    r1 = O.solve_condensed(p, O.problem(p, [0, 0.2, 0, 8.0], ref2, 10.0))
+    assert abs(r0["cost"] - r1["cost"]) < 1e-9 * max(1, r0["cost"]) and np.abs(r0["U"] - r1["U"]).max() < 1e-9
+    # cost() restated by hand, with the reference's index ranges (:97-103)
+    U, X = r0["U"], r0["X"]
+    J = sum(w[0] * (X[k, 0] - ref[k, 0]) ** 2 + w[1] * (X[k, 1] - ref[k, 1]) ** 2 + w[2] * (X[k, 2] - ref[k, 2]) ** 2
+            for k in range(1, N + 1))
+    J += w[3] * sum((X[k, 3] - 10.0) ** 2 for k in range(1, N))  # i = 2:N  -> terminal v excluded
+    J += w[4] * np.sum(np.diff(U[:, 0]) ** 2) + w[5] * np.sum(np.diff(U[:, 1]) ** 2)
+    assert abs(J - r0["cost"]) < 1e-9 * max(1.0, J)
+
+
+def test_infeasible_initial_speed(oracle):
+    """Q5: v[1] is pinned to v0 and bounded to [0, 20] -> v0 outside is infeasible; output stays finite and in the box."""
+    O = oracle
+    p = O.params(8)
+    r = O.solve_condensed(p, O.problem(p, [0, 0, 0, 25.0], line_ref(8), 15.0))
+    assert r["status"] == 2 and np.isfinite(r["U"]).all() and np.abs(r["U"][:, 0]).max() <= 1.0
+    r = O.solve_condensed(p, O.problem(p, [0, 0, 0, 0.0], line_ref(8), 15.0, (-0.9, 0.0)))  # standing, hard braking held
+    assert r["status"] == 2
+
+
+@pytest.mark.parametrize("N", [8, 20])
+def test_gradient_and_hessian_against_finite_differences(oracle, N):
+    O = oracle
+    p = O.params(N, (9, 9, 10, 2.0, 100, 1000, 0.5, 3.0))
+    rng = np.random.default_rng(3)
+    k = np.arange(N + 1)
+    ref = np.stack([8 * 0.2 * k, 0.05 * k ** 1.5, 0.02 * k], axis=1)
+    q = O.problem(p, [0.1, -0.4, 0.05, 7.0], ref, 8.0)
+    U = np.stack([rng.uniform(-0.5, 0.5, N), rng.uniform(-0.2, 0.2, N)], axis=1)
+    g = O.grad(p, q, U)
+    H, g2, J = O.condense(p, q, U, hessian=1)
+    assert np.abs(g - g2).max() < 1e-9 * max(1, np.abs(g).max())
+    assert abs(J - O.cost(p, q, U)) < 1e-12 * max(1, J)
+    h = 1e-6
+    gfd = np.zeros(2 * N)
+    Hfd = np.zeros((2 * N, 2 * N))
+    for j in range(2 * N):
+        e = np.zeros(2 * N)
+        e[j] = h
+        Up, Um = (U.ravel() + e).reshape(N, 2), (U.ravel() - e).reshape(N, 2)
+        gfd[j] = (O.cost(p, q, Up) - O.cost(p, q, Um)) / (2 * h)
+        Hfd[:, j] = (O.grad(p, q, Up) - O.grad(p, q, Um)) / (2 * h)
+    assert np.abs(g - gfd).max() < 1e-5 * max(1, np.abs(g).max())
+    assert np.abs(H - Hfd).max() < 1e-6 * np.abs(H).max()
+    assert np.abs(H - H.T).max() < 1e-9 * np.abs(H).max()
+    Hgn = O.condense(p, q, U, hessian=0)[0]
+    assert np.linalg.eigvalsh(Hgn).min() > -1e-8 * np.abs(Hgn).max()  # Gauss-Newton part is PSD
+
+
+@pytest.mark.parametrize("N", [8, 20, 50])
+def test_condensed_oracle_matches_golden(oracle, N):
+    """fixtures: tests/golden/kmpc_N*.npz (oracle/make_golden.py; three solvers agreed to < 2e-7 relative)."""
+    O = oracle
+    G = np.load(os.path.join(GOLD, "kmpc_N%d.npz" % N))
+    p = O.params(N, G["weights"])
+    r = O.solve_condensed_batch(p, G["z0"], G["ref"], G["v_target"], G["u_prev"], nthreads=8)
+    assert (r["status"] == 0).all()
+    Jg = G["J_ipopt_like"]
+    assert (np.abs(r["cost"] - Jg) <= 1e-6 * np.maximum(1.0, np.abs(Jg))).all()
+    assert np.abs(G["J_scipy"] - Jg).max() <= 2e-7 * np.maximum(1.0, np.abs(Jg)).max()
+    assert r["viol"].max() <= 1e-8 + 1e-12
+    assert np.abs(r["U"][:, 0, :] - G["U_ipopt_like"][:, 0, :]).max() < 1e-4
+    # every solution is a certified KKT point of the state-eliminated NLP
+    for b in range(0, len(Jg), 5):
+        q = O.problem(p, G["z0"][b], G["ref"][b], G["v_target"][b], G["u_prev"][b])
+        rs = O.solve_condensed(p, q)
+        c = O.certify(p, q, rs["U"], rs["lam"])
+        scale = max(1.0, np.abs(O.grad(p, q, rs["U"])).max())
+        assert c["stationarity"] <= 1e-6 * scale and c["violation"] <= 1e-8 + 1e-12 and c["lam_min"] >= 0
+
+
+def test_ipopt_like_full_space_matches_golden(oracle):
+    """the independent full-space Ipopt-style restatement reproduces the fixtures (N = 8 subset; seconds)."""
+    from oracle import ipopt_like as IL
+    G = np.load(os.path.join(GOLD, "kmpc_N8.npz"))
+    for b in (0, 1, 2, 3, 5, 9, 17):
+        r = IL.solve_problem(8, G["z0"][b], G["ref"][b], G["v_target"][b], G["u_prev"][b], weights=tuple(G["weights"]))
+        assert r["status"] == 0
+        assert abs(r["cost"] - G["J_ipopt_like"][b]) <= 1e-8 * max(1.0, abs(G["J_ipopt_like"][b]))
+        assert r["constr_viol"] < 1e-9
+
+
+def test_warm_start_reaches_same_optimum(oracle):
+    O = oracle
+    N = 20
+    p = O.params(N)
+    k = np.arange(N + 1)
+    s = 9.0 * 0.2 * k
+    ref = np.stack([30 * np.sin(s / 30), 30 * (1 - np.cos(s / 30)), s / 30], axis=1)
+    q = O.problem(p, [0, 0.4, 0.02, 8.5], ref, 9.0, (0.1, 0.05))
+    cold = O.solve_condensed(p, q)
+    warm = O.solve_condensed(p, q, O.opts(warm=1), U0=cold["U"])
+    assert warm["status"] == 0 and abs(warm["cost"] - cold["cost"]) < 1e-6 * max(1, cold["cost"])
+    assert warm["iters"] <= cold["iters"]
