@@ -69,7 +69,7 @@ typedef struct kmpc_config {
     double warm_push;    /* weight of the interior point blended into a warm start */
     double warm_mu;      /* mu_init used with a warm start */
     int32_t max_ls;      /* back-tracking trial points per iteration */
-    int32_t reserved;
+    int32_t kernel_variant; /* 0 = auto (compile-time-horizon kernel when one is built for N, else generic), 1 = generic */
 } kmpc_config;
 
 typedef struct kmpc_handle kmpc_handle;

@@ -15,6 +15,8 @@
 template <typename T> hipError_t kmpc_launch_solve(const KP &, const KIO<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_condense(const KP &, const KDbg<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_probe(const T *, const T *, T *, hipStream_t);
+template <typename T> bool kmpc_fast_available(int N);
+template <typename T> hipError_t kmpc_launch_solve_fast(const KP &, const KIO<T> &, hipStream_t);
 
 struct kmpc_handle {
     kmpc_config cfg;
@@ -28,6 +30,10 @@ struct kmpc_handle {
 };
 
 static std::string g_create_err;
+static unsigned long long *g_stamps = nullptr;  // set by kmpc_debug_set_stamps in diagnostic builds
+#ifdef KMPC_STAMPS
+extern "C" int32_t kmpc_debug_set_stamps(void *p) { g_stamps = (unsigned long long *)p; return 0; }
+#endif
 
 static int fail(kmpc_handle *h, int code, const char *fmt, ...)
 {
@@ -83,7 +89,8 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
     if (cfg->dtype != KMPC_F64 && cfg->dtype != KMPC_F32) return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: bad dtype %d", cfg->dtype);
     if (!(cfg->dt > 0) || !(cfg->dt_control > 0) || !(cfg->L_b > 0) || !(cfg->L_a + cfg->L_b > 0) ||
         !(cfg->v_max > cfg->v_min) || !(cfg->a_max > 0) || !(cfg->steer_max > 0) || !(cfg->steer_max < 1.5) ||
-        !(cfg->a_dmax > 0) || !(cfg->steer_dmax > 0) || cfg->max_iter < 1 || cfg->max_ls < 1 || !(cfg->tol > 0))
+        !(cfg->a_dmax > 0) || !(cfg->steer_dmax > 0) || cfg->max_iter < 1 || cfg->max_ls < 1 || !(cfg->tol > 0) ||
+        cfg->kernel_variant < 0 || cfg->kernel_variant > 1)
         return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: invalid model / solver parameter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_create: no HIP device");
@@ -162,8 +169,10 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
     io.z0 = (const T *)z0; io.ref = (const T *)ref; io.vt = (const T *)vt; io.up = (const T *)up;
     io.warmU = (T *)warmU; io.u0 = (T *)u0; io.status = status; io.cost = (T *)cost; io.viol = (T *)viol;
     io.iters = iters; io.outU = (T *)outU; io.outX = (T *)outX;
+    io.stamps = g_stamps;
     const KP P = make_kp(h, B, warm && warmU ? 1 : 0, -1);
-    HIPCHK(h, kmpc_launch_solve<T>(P, io, st));
+    if (h->cfg.kernel_variant == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));
+    else HIPCHK(h, kmpc_launch_solve<T>(P, io, st));
     return KMPC_OK;
 }
 

@@ -1,0 +1,124 @@
+// kmpc_common.h -- device primitives shared by the generic (kmpc_kernels.hip) and the
+// compile-time-horizon (kmpc_fast.hip) solver kernels.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "kmpc_device.h"
+
+#define DEV __device__ __forceinline__
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Real;
+template <> struct Real<double> {
+    typedef double4_t acc_t;
+    static DEV acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // C/D of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+    static DEV int row_of(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+    static DEV int q_of_row(int rr) { return rr & 3; }
+    static DEV int reg_of_row(int rr) { return rr >> 2; }
+    static DEV void sincos_(double x, double *s, double *c) { sincos(x, s, c); }
+    static DEV double eps() { return 2.220446049250313e-16; }
+    static DEV double tiny() { return 1e-300; }
+};
+template <> struct Real<float> {
+    typedef float4_t acc_t;
+    static DEV acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // C/D of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4*(lane>>4) + reg
+    static DEV int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+    static DEV int q_of_row(int rr) { return rr >> 2; }
+    static DEV int reg_of_row(int rr) { return rr & 3; }
+    static DEV void sincos_(float x, float *s, float *c) { sincosf(x, s, c); }
+    static DEV float eps() { return 1.1920929e-07f; }
+    static DEV float tiny() { return 1e-30f; }
+};
+
+// ---- wave primitives (64 lanes, one wave per workgroup) -------------------------------------
+template <typename T> DEV T wave_sum(T x) { for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o); return x; }
+template <typename T> DEV T wave_max(T x) { for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o)); return x; }
+template <typename T> DEV T wave_min(T x) { for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o)); return x; }
+template <typename T> DEV T scan_prefix(T x, int lane) {  // inclusive, lane 0 -> 63
+    for (int d = 1; d < 64; d <<= 1) { T t = __shfl_up(x, d); if (lane >= d) x += t; }
+    return x;
+}
+template <typename T> DEV T scan_suffix(T x, int lane) {  // inclusive, lane 63 -> 0
+    for (int d = 1; d < 64; d <<= 1) { T t = __shfl_down(x, d); if (lane + d < 64) x += t; }
+    return x;
+}
+#define WSYNC() __syncthreads()
+
+// phase stamps: diagnostic builds only (-DKMPC_STAMPS); the shipped library has none
+#ifdef KMPC_STAMPS
+#define STAMP_DECL unsigned long long st_t0_ = __builtin_readcyclecounter(), st_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc_[i] += t_ - st_t0_; st_t0_ = t_; } while (0)
+#define STAMP_OUT(ptr, b) do { if ((ptr) && threadIdx.x == 0) for (int i_ = 0; i_ < 12; ++i_) (ptr)[(size_t)(b) * 12 + i_] = st_acc_[i_]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_OUT(ptr, b)
+#endif
+
+
+// ---- DPP / readlane primitives (no LDS traffic) ----------------------------------------------
+// dpp_ctrl encodings (GFX9 / CDNA): row_shl:n 0x100+n, row_shr:n 0x110+n, row_bcast15 0x142, row_bcast31 0x143
+template <int CTRL, int RM> DEV double dpp_mov0(double x) {  // value of the source lane, 0 where invalid / masked
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, RM, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, RM, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int RM> DEV float dpp_mov0(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, RM, 0xf, true));
+}
+template <int CTRL> DEV double dpp_mov_keep(double x, double ident) {  // source lane value, `ident` where invalid
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(x), CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> DEV float dpp_mov_keep(float x, float ident) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+DEV double readlane_(double x, int l) {  // l wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+DEV float readlane_(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+
+// inclusive prefix sum over lanes 0..63 (ROWS = number of 16-lane rows that carry data)
+template <int ROWS, typename T> DEV T dpp_scan_prefix(T x) {
+    T v = x + dpp_mov0<0x111, 0xf>(x);
+    v += dpp_mov0<0x112, 0xf>(x);
+    v += dpp_mov0<0x113, 0xf>(x);
+    v += dpp_mov0<0x114, 0xf>(v);
+    v += dpp_mov0<0x118, 0xf>(v);
+    if (ROWS > 1) v += dpp_mov0<0x142, 0xa>(v);
+    if (ROWS > 2) v += dpp_mov0<0x143, 0xc>(v);
+    return v;
+}
+// inclusive suffix sum (lane k gets sum over lanes >= k)
+template <int ROWS, typename T> DEV T dpp_scan_suffix(T x, int lane) {
+    T v = x + dpp_mov0<0x101, 0xf>(x);
+    v += dpp_mov0<0x102, 0xf>(x);
+    v += dpp_mov0<0x103, 0xf>(x);
+    v += dpp_mov0<0x104, 0xf>(v);
+    v += dpp_mov0<0x108, 0xf>(v);
+    if (ROWS > 1) {
+        const T t1 = readlane_(v, 16);
+        const T t2 = ROWS > 2 ? readlane_(v, 32) : (T)0, t3 = ROWS > 3 ? readlane_(v, 48) : (T)0;
+        const int row = lane >> 4;
+        v += row == 0 ? t1 + t2 + t3 : (row == 1 ? t2 + t3 : (row == 2 ? t3 : (T)0));
+    }
+    return v;
+}
+template <typename T> DEV T dpp_sum(T x) { return readlane_(dpp_scan_prefix<4>(x), 63); }
+template <typename T> DEV T dpp_max(T x) {
+    const T ninf = -INFINITY;
+    x = fmax(x, dpp_mov_keep<0x111>(x, ninf));
+    x = fmax(x, dpp_mov_keep<0x112>(x, ninf));
+    x = fmax(x, dpp_mov_keep<0x114>(x, ninf));
+    x = fmax(x, dpp_mov_keep<0x118>(x, ninf));
+    return fmax(fmax(readlane_(x, 15), readlane_(x, 31)), fmax(readlane_(x, 47), readlane_(x, 63)));
+}
+template <typename T> DEV T dpp_min(T x) { return -dpp_max(-x); }

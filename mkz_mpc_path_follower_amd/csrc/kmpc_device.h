@@ -22,6 +22,7 @@ struct KIO {
     T *cost, *viol;
     int32_t *iters;
     T *outU, *outX;
+    unsigned long long *stamps;  // diagnostic builds only (KMPC_STAMPS), else NULL
 };
 
 template <typename T>

@@ -1,0 +1,769 @@
+// kmpc_fast.hip -- compile-time-horizon solver kernel for gfx950 (n + 1 = 2N + 1 <= 64 lanes).
+//
+// Same algorithm and same results as the generic kernel in kmpc_kernels.hip (one wavefront per
+// problem; see the header there), restructured so that a lone wave is not stalled on LDS /
+// ds_bpermute round trips and so that 4 waves fit per SIMD:
+//   * every loop over stages / columns is fully unrolled: register files are indexed statically,
+//     per-stage scalars are broadcast with v_readlane (constant lane), no LDS staging of them;
+//   * scans and reductions run on DPP (row_shr / row_shl / row_bcast), not ds_bpermute;
+//   * the condensed Hessian stays in the MFMA accumulators until it is written ONCE, with the
+//     barrier terms, into a packed column-major LDS image (n(n+3)/2 words, 6.9 KB at N = 20);
+//   * Cholesky keeps row i of K in the registers of lane i; column j is broadcast through its
+//     packed LDS slot (uniform-address reads); the right-hand side rides along as row n, so the
+//     forward substitution is free; the backward substitution chains v_readlane + FMA on
+//     register-resident columns.
+#include "kmpc_common.h"
+
+#define WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+DEV void pin(double &x) { asm volatile("" : "+v"(x)); }
+DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
+
+DEV double rsqrt_(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * y, y, 1.0);
+    y = fma(y * e, fma(e, 0.375, 0.5), y);
+    e = fma(-d * y, y, 1.0);
+    return fma(y * e, 0.5, y);
+}
+DEV float rsqrt_(float d) {
+    float y = __builtin_amdgcn_rsqf(d);
+    const float e = fmaf(-d * y, y, 1.0f);
+    return fmaf(y * e, fmaf(e, 0.375f, 0.5f), y);
+}
+
+// sin / cos for |x| <= 0.8 (tyre angles are bounded by steer_max <= 0.5 rad): Taylor to x^17 / x^18,
+// truncation < 2e-19 relative; larger arguments (non-default steer_max) take the libm path
+template <typename T> DEV void sincos_small(T x, T *s, T *c) {
+    if (fabs(x) > (T)0.8) { Real<T>::sincos_(x, s, c); return; }
+    const T z = x * x;
+    T ps = (T)(1.0 / 355687428096000.0);
+    ps = fma(ps, z, (T)(-1.0 / 1307674368000.0));
+    ps = fma(ps, z, (T)(1.0 / 6227020800.0));
+    ps = fma(ps, z, (T)(-1.0 / 39916800.0));
+    ps = fma(ps, z, (T)(1.0 / 362880.0));
+    ps = fma(ps, z, (T)(-1.0 / 5040.0));
+    ps = fma(ps, z, (T)(1.0 / 120.0));
+    ps = fma(ps, z, (T)(-1.0 / 6.0));
+    *s = fma(x * z, ps, x);
+    T pc = (T)(-1.0 / 6402373705728000.0);
+    pc = fma(pc, z, (T)(1.0 / 20922789888000.0));
+    pc = fma(pc, z, (T)(-1.0 / 87178291200.0));
+    pc = fma(pc, z, (T)(1.0 / 479001600.0));
+    pc = fma(pc, z, (T)(-1.0 / 3628800.0));
+    pc = fma(pc, z, (T)(1.0 / 40320.0));
+    pc = fma(pc, z, (T)(-1.0 / 720.0));
+    pc = fma(pc, z, (T)(1.0 / 24.0));
+    pc = fma(pc, z, (T)(-0.5));
+    *c = fma(z, pc, (T)1);
+}
+
+// sin / cos for |x| up to ~1e3 rad (headings are unwrapped relative to the reference, a few rad):
+// Cody-Waite reduction by pi/2 in two pieces + the same polynomials on |r| <= pi/4
+template <typename T> DEV void sincos_mid(T x, T *s, T *c) {
+    if (!(fabs(x) < (T)1000)) { Real<T>::sincos_(x, s, c); return; }
+    const T k = rint(x * (T)0.63661977236758134308);
+    T r = fma(-k, (T)1.57079632679489655800e+00, x);
+    r = fma(-k, (T)6.12323399573676603587e-17, r);
+    T sr, cr;
+    sincos_small(r, &sr, &cr);
+    const int q = (int)k & 3;
+    const T ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+
+template <typename T> struct StageF {  // lane k: state k / input k at the evaluated point
+    T a, d, v, x, y, psi, c, s, sinb, cosb, b1, b2, ex, ey, ep, ev;
+};
+// linearisation scalars of stage k, parked in LDS (16 words per stage, aliasing the K image, which is
+// idle between a factorisation and the next build_K): A02 A03 A12 A13 A23 Bdx Bdy Bdp mpp mpv mpd mvd mdd
+constexpr int LIN_STRIDE = 16;
+
+template <typename T, int N> struct FastSolver {
+    static constexpr int n = 2 * N, R = 2 * (N - 1), nf = 5 * N - 2;
+    static constexpr int NF = (nf + 63) / 64;
+    static constexpr int NT = (n + 15) / 16, NTT = NT * (NT + 1) / 2;
+    static constexpr int SROWS = (N + 1 + 15) / 16;  // 16-lane rows that carry stage data
+    static constexpr int NROWS = (n + 1 + 15) / 16;  // rows that carry n-vector data
+    static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
+    static_assert(n + 1 <= 64, "fast kernel needs 2N + 1 <= 64");
+    typedef typename Real<T>::acc_t acc_t;
+    static_assert(LIN_STRIDE * (N + 1) <= LC, "stage scalars must fit in the K image");
+    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64; }
+    // start of column j minus j, so that element (row i, col j) lives at offc(j) + i
+    static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
+    static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
+
+    const KP &P;
+    int lane;  // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the
+               // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
+    T *Lc, *xb, *wb, *cb;
+    T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp;
+    T dt, dtc, Lb, rr_, Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
+
+    DEV FastSolver(const KP &p, unsigned char *smem) : P(p), lane(threadIdx.x)
+    {
+        Lc = reinterpret_cast<T *>(smem);
+        xb = Lc + ((LC + 1) & ~1);
+        wb = xb + 64;
+        cb = wb + 64 * NF;
+        dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
+        Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
+        Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
+    }
+
+    DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)
+    {
+        x0 = z0[4 * (size_t)b]; y0 = z0[4 * (size_t)b + 1]; psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
+        vt = vtp[b];
+        up0 = upp[2 * (size_t)b]; up1 = upp[2 * (size_t)b + 1];
+        rx = ry = rp = (T)0;
+        if (lane <= N) {
+            const T *r = ref + ((size_t)b * (N + 1) + lane) * 3;
+            rx = r[0]; ry = r[1]; rp = r[2];
+        }
+    }
+
+    DEV void form_bounds(int f, T &bu, T &bl) const
+    {
+        const T relax = (T)P.relax;
+        if (f < n) {
+            const T ub = (f & 1) ? (T)P.steer_max : (T)P.a_max;
+            bu = bl = ub + relax * fmax((T)1, ub);
+        } else if (f < n + R) {
+            const int r = f - n, jj = r & 1, kk = r >> 1;
+            const T d = (jj ? (T)P.steer_dmax : (T)P.a_dmax) * (kk == 0 ? dtc : dt);
+            const T u = kk == 0 ? (jj ? up1 : up0) : (T)0;
+            bu = d + relax * fmax((T)1, d) + u; bl = d + relax * fmax((T)1, d) - u;
+        } else if (f < nf) {
+            bu = (T)P.v_max + relax * fmax((T)1, fabs((T)P.v_max)) - v0;
+            bl = -(T)P.v_min + relax * fmax((T)1, fabs((T)P.v_min)) + v0;
+        } else { bu = bl = (T)1; }
+    }
+    DEV T form_relax(int f, bool upper) const
+    {
+        const T relax = (T)P.relax;
+        if (f < n) return relax * fmax((T)1, (f & 1) ? (T)P.steer_max : (T)P.a_max);
+        if (f < n + R) { const int r = f - n; return relax * fmax((T)1, ((r & 1) ? (T)P.steer_dmax : (T)P.a_dmax) * ((r >> 1) == 0 ? dtc : dt)); }
+        return relax * fmax((T)1, fabs(upper ? (T)P.v_max : (T)P.v_min));
+    }
+
+    // y_f = a_f^T x   (x: lane j holds x_j)
+    DEV void forms_apply(T x, T (&y)[NF])
+    {
+        if (lane < n) xb[lane] = x;
+        WSYNC();
+        T a = lane < N ? xb[2 * lane] : (T)0;
+        a = dpp_scan_prefix<SROWS>(a);
+        if (lane < N) cb[lane] = a;
+        WSYNC();
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = lane + 64 * i;
+            T v = (T)0;
+            if (f < n) v = xb[f];
+            else if (f < n + R) { const int r = f - n; v = r < 2 ? xb[r] : xb[r + 2] - xb[r]; }
+            else if (f < nf) v = dt * cb[f - n - R];
+            y[i] = v;
+        }
+        WSYNC();
+    }
+    DEV void stage_form_weights(const T (&w)[NF])
+    {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; if (f < nf) wb[f] = w[i]; }
+        WSYNC();
+        T s = lane < N ? wb[n + R + lane] : (T)0;
+        s = dpp_scan_suffix<SROWS>(s, lane);
+        if (lane < N) cb[lane] = s;
+        WSYNC();
+    }
+    DEV T forms_applyT(const T (&w)[NF])  // returns (A^T w)_lane
+    {
+        stage_form_weights(w);
+        T o = (T)0;
+        const int j = lane;
+        if (j < n) {
+            o = wb[j];
+            if (j < 2) o += wb[n + j];
+            if (j >= 4) o += wb[n + j - 2];
+            if (j >= 2 && j < R) o -= wb[n + j];
+            if (!(j & 1)) o += dt * cb[j >> 1];
+        }
+        WSYNC();
+        return o;
+    }
+    DEV T gram_entry(int row, int col) const
+    {
+        T g = (T)0;
+        if (row == col) {
+            g = wb[row];
+            if (row < 2) g += wb[n + row];
+            if (row >= 4) g += wb[n + row - 2];
+            if (row >= 2 && row < R) g += wb[n + row];
+        } else if (row == col + 2 && col >= 2 && col < R) {
+            g = -wb[n + col];
+        }
+        if (!((row | col) & 1)) g += dt * dt * cb[row >> 1];
+        return g;
+    }
+    DEV T input_hess(int row, int col) const
+    {
+        const int jj = row & 1, k = row >> 1;
+        const T Cu = jj ? Cd : Ca, Cdl = jj ? Cdd : Cda;
+        if (row == col) return (T)2 * Cu + (T)2 * Cdl * (T)((k > 0) + (k < N - 1));
+        if (row == col + 2) return -(T)2 * Cdl;
+        return (T)0;
+    }
+
+    // roll-out (MKZMPCPathFollower.jl:115-122 as prefix scans) + objective (:97-103) at U (lane j: U_j)
+    DEV T eval(T U, StageF<T> &S)
+    {
+        if (lane < n) xb[lane] = U;
+        WSYNC();
+        const int k = lane;
+        const bool st = k < N;
+        const T a = st ? xb[2 * k] : (T)0, d = st ? xb[2 * k + 1] : (T)0;
+        const T an = (k + 1 < N) ? xb[2 * k + 2] : a, dn = (k + 1 < N) ? xb[2 * k + 3] : d;
+        WSYNC();
+        S.a = a; S.d = d;
+        const T ia = dpp_scan_prefix<SROWS>(a);
+        const T v = v0 + dt * (ia - a);
+        T sd, cd;
+        sincos_small(d, &sd, &cd);
+        const T Dn = cd * cd + rr_ * rr_ * sd * sd;
+        const T rs = rsqrt_(Dn);
+        S.sinb = rr_ * sd * rs;
+        S.cosb = cd * rs;
+        S.b1 = rr_ / Dn;
+        S.b2 = rr_ * ((T)1 - rr_ * rr_) * ((T)2 * sd * cd) / (Dn * Dn);
+        const T wp = st ? v * S.sinb : (T)0;
+        const T ip = dpp_scan_prefix<SROWS>(wp);
+        const T psi = psi0 + (dt / Lb) * (ip - wp);
+        T sp, cp;
+        sincos_mid(psi, &sp, &cp);
+        S.c = cp * S.cosb - sp * S.sinb;
+        S.s = sp * S.cosb + cp * S.sinb;
+        const T wx = st ? v * S.c : (T)0, wy = st ? v * S.s : (T)0;
+        const T ix = dpp_scan_prefix<SROWS>(wx), iy = dpp_scan_prefix<SROWS>(wy);
+        S.x = x0 + dt * (ix - wx);
+        S.y = y0 + dt * (iy - wy);
+        S.v = v; S.psi = psi;
+        const bool cs = (k >= 1 && k <= N);
+        S.ex = cs ? S.x - rx : (T)0;
+        S.ey = cs ? S.y - ry : (T)0;
+        S.ep = cs ? psi - rp : (T)0;
+        S.ev = (k >= 1 && k <= N - 1) ? v - vt : (T)0;
+        T Jl = Cx * S.ex * S.ex + Cy * S.ey * S.ey + Cp * S.ep * S.ep + Cv * S.ev * S.ev;
+        if (st) Jl += Ca * a * a + Cd * d * d;
+        if (k < N - 1) Jl += Cda * (an - a) * (an - a) + Cdd * (dn - d) * (dn - d);
+        return dpp_sum(Jl);
+    }
+
+    // costates by suffix scans -> gradient (returned, lane j: g_j); per-stage scalars go to LDS (Lc alias)
+    DEV T linearize(const StageF<T> &S, bool exact)
+    {
+        const int k = lane;
+        const bool st = k < N;
+        const T lx = (T)2 * Cx * S.ex, ly = (T)2 * Cy * S.ey, lp = (T)2 * Cp * S.ep, lv = (T)2 * Cv * S.ev;
+        const T px = dpp_scan_suffix<SROWS>(lx, lane), py = dpp_scan_suffix<SROWS>(ly, lane);
+        const T px1 = dpp_mov0<0x130, 0xf>(px), py1 = dpp_mov0<0x130, 0xf>(py);  // wave_shl:1 -> value of lane+1
+        const T A02 = st ? -dt * S.v * S.s : (T)0, A12 = st ? dt * S.v * S.c : (T)0;
+        const T A03 = st ? dt * S.c : (T)0, A13 = st ? dt * S.s : (T)0, A23 = st ? dt / Lb * S.sinb : (T)0;
+        const T tp = lp + (st ? A02 * px1 + A12 * py1 : (T)0);
+        const T pp = dpp_scan_suffix<SROWS>(tp, lane);
+        const T pp1 = dpp_mov0<0x130, 0xf>(pp);
+        const T tv = lv + (st ? A03 * px1 + A13 * py1 + A23 * pp1 : (T)0);
+        const T pv = dpp_scan_suffix<SROWS>(tv, lane);
+        const T pv1 = dpp_mov0<0x130, 0xf>(pv);
+        const T Bdx = st ? -dt * S.v * S.s * S.b1 : (T)0, Bdy = st ? dt * S.v * S.c * S.b1 : (T)0;
+        const T Bdp = st ? dt * S.v / Lb * S.cosb * S.b1 : (T)0;
+        const T aprev = dpp_mov0<0x138, 0xf>(S.a), dprev = dpp_mov0<0x138, 0xf>(S.d);  // wave_shr:1 -> lane-1
+        const T anext = dpp_mov0<0x130, 0xf>(S.a), dnext = dpp_mov0<0x130, 0xf>(S.d);
+        T ga = dt * pv1 + (T)2 * Ca * S.a, gd = Bdx * px1 + Bdy * py1 + Bdp * pp1 + (T)2 * Cd * S.d;
+        if (k >= 1) { ga += (T)2 * Cda * (S.a - aprev); gd += (T)2 * Cdd * (S.d - dprev); }
+        if (k < N - 1) { ga -= (T)2 * Cda * (anext - S.a); gd -= (T)2 * Cdd * (dnext - S.d); }
+        if (st) { xb[2 * k] = ga; xb[2 * k + 1] = gd; }
+        T mpp = 0, mpv = 0, mpd = 0, mvd = 0, mdd = 0;
+        if (exact && st) {
+            const T v = S.v, c = S.c, s = S.s, b1 = S.b1, b2 = S.b2;
+            mpp = px1 * (-dt * v * c) + py1 * (-dt * v * s);
+            mpv = px1 * (-dt * s) + py1 * (dt * c);
+            mpd = px1 * (-dt * v * c * b1) + py1 * (-dt * v * s * b1);
+            mvd = px1 * (-dt * s * b1) + py1 * (dt * c * b1) + pp1 * (dt / Lb * S.cosb * b1);
+            mdd = px1 * (-dt * v * (c * b1 * b1 + s * b2)) + py1 * (dt * v * (-s * b1 * b1 + c * b2)) +
+                  pp1 * (dt * v / Lb * (-S.sinb * b1 * b1 + S.cosb * b2));
+        }
+        {
+            T *q = Lc + LIN_STRIDE * (k <= N ? k : N);
+            T *dmy = xb + 48;  // lanes > N write nowhere that matters
+            T *w0 = k <= N ? q : dmy;
+            w0[0] = A02; w0[1] = A03;
+            if (k <= N) { q[2] = A12; q[3] = A13; q[4] = A23; q[5] = Bdx; q[6] = Bdy; q[7] = Bdp;
+                          q[8] = mpp; q[9] = mpv; q[10] = mpd; q[11] = mvd; q[12] = mdd; }
+        }
+        WSYNC();
+        const T g = lane < n ? xb[lane] : (T)0;
+        WSYNC();
+        return g;
+    }
+
+    // condensing on the matrix cores, stage loop fully unrolled, stage scalars by v_readlane
+    DEV void condense(bool exact, acc_t (&acc)[NTT])
+    {
+        const int kk = lane >> 4, c = lane & 15;
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        T own[NT], gps[NT], gv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) own[t] = gps[t] = gv[t] = (T)0;
+#pragma unroll
+        for (int s = 0; s <= N; ++s) {
+            if (s >= 1) {
+                const int sp = s - 1;
+                const T *q = Lc + LIN_STRIDE * sp;  // uniform-address LDS reads
+                const T A02 = q[0], A03 = q[1], A12 = q[2], A13 = q[3], A23 = q[4], Bdx = q[5], Bdy = q[6], Bdp = q[7];
+                const T cA = kk == 0 ? A02 : (kk == 1 ? A12 : (T)0);
+                const T cB = kk == 0 ? A03 : (kk == 1 ? A13 : (kk == 2 ? A23 : (T)0));
+                const T bo = kk == 0 ? Bdx : (kk == 1 ? Bdy : (kk == 2 ? Bdp : (T)0));
+                const int col0 = 2 * sp;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (16 * t < col0) {  // tiles that already hold columns
+                        own[t] += cA * gps[t] + cB * gv[t];
+                        gps[t] += A23 * gv[t];
+                    }
+                    if (t == (col0 >> 4)) {
+                        const int col = 16 * t + c;
+                        if (col == col0) { own[t] = kk == 3 ? dt : (T)0; gps[t] = (T)0; gv[t] = dt; }
+                        if (col == col0 + 1) { own[t] = bo; gps[t] = Bdp; gv[t] = (T)0; }
+                    }
+                }
+                const T mpp = (exact && s < N) ? Lc[LIN_STRIDE * s + 8] : (T)0;
+                const T mpv = (exact && s < N) ? Lc[LIN_STRIDE * s + 9] : (T)0;
+                const T Cvs = s <= N - 1 ? Cv : (T)0;
+                const T dco = kk == 0 ? (T)2 * Cx : (kk == 1 ? (T)2 * Cy : (kk == 2 ? (T)2 * Cp + mpp : (T)2 * Cvs));
+                const T oco = kk >= 2 ? mpv : (T)0;
+                T bop[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bop[t] = dco * own[t] + oco * (kk == 2 ? gv[t] : gps[t]);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+                    if (16 * ti < 2 * s) {
+#pragma unroll
+                        for (int tj = 0; tj <= ti; ++tj)
+                            acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[ti * (ti + 1) / 2 + tj]);
+                    }
+            }
+            if (s < N) {  // row 2s+1 (d_f of stage s) of the second-order term
+                const T mpd = exact ? Lc[LIN_STRIDE * s + 10] : (T)0, mvd = exact ? Lc[LIN_STRIDE * s + 11] : (T)0,
+                        mdd = exact ? Lc[LIN_STRIDE * s + 12] : (T)0;
+                const int rho = 2 * s + 1, rt = rho >> 4, rr = rho & 15;
+                const bool mine = kk == Real<T>::q_of_row(rr);
+                const int reg = Real<T>::reg_of_row(rr);
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+                    if (tj <= rt) {
+                        T val = mpd * gps[tj] + mvd * gv[tj];
+                        if (tj == rt && c == rr) val += mdd;
+                        if (!mine) val = (T)0;
+                        acc[rt * (rt + 1) / 2 + tj][reg] += val;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the unrolled stages from being interleaved (register pressure)
+        }
+    }
+
+    // packed KKT image: lower triangle of sc*(H + input Hessian) + A^T W A + reg*I, and the rhs as row n.
+    // Needs stage_form_weights(w) done (wb = form weights, cb = suffix sums of the speed weights).
+    // The dense part comes from the accumulators; A^T W A is structured: the speed rows add
+    // dt^2 * S[row/2] to every (even,even) entry -- (even,even) is a per-lane property in the MFMA C
+    // layout -- and the box / rate rows touch only the diagonal and the (j+2, j) entries, which lane j
+    // adds afterwards together with the input-cost Hessian (MKZMPCPathFollower.jl:99-102).
+    DEV void build_K(const acc_t (&acc)[NTT], T sc, T reg, T rhs)
+    {
+        const int c = lane & 15, q = lane >> 4;
+        const bool ee = !((Real<T>::row_of(lane, 0) | c) & 1) && !((Real<T>::row_of(lane, 1)) & 1);  // rows q+4r / 4q+r: parity
+        // (for f64 row = q + 4r: parity of row == parity of q for every r; for f32 row = 4q + r: parity follows r)
+        const T dt2 = dt * dt;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + Real<T>::row_of(lane, r);
+                const bool rowev = !(row & 1) && !(c & 1);
+                const T sp = rowev ? dt2 * cb[(row < n ? row : 0) >> 1] : (T)0;
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj) {
+                    const int col = 16 * tj + c;
+                    const bool ok = row < n && col <= row;
+                    T *dst = ok ? Lc + offc_rt(ok ? col : 0) + row : xb + lane;
+                    *dst = sc * acc[ti * (ti + 1) / 2 + tj][r] + sp;
+                }
+            }
+        (void)ee; (void)q;
+        WSYNC();
+        if (lane < n) {
+            const int j = lane, jj = j & 1, k = j >> 1;
+            const T Cu = jj ? Cd : Ca, Cdl = jj ? Cdd : Cda;
+            T dg = wb[j] + sc * ((T)2 * Cu + (T)2 * Cdl * (T)((k > 0) + (k < N - 1))) + reg;
+            if (j < 2) dg += wb[n + j];
+            if (j >= 4) dg += wb[n + j - 2];
+            const bool rate = j >= 2 && j < R;
+            const T wr = rate ? wb[n + j] : (T)0;
+            dg += wr;
+            T *pd = Lc + offc_rt(j);
+            pd[j] += dg;
+            if (j + 2 < n) pd[j + 2] += -wr - sc * (T)2 * Cdl;
+            pd[n] = rhs;
+        }
+        WSYNC();
+    }
+
+    // In-register Cholesky of the packed image + both substitutions; x (lane j) = K^{-1} rhs.
+    // Split-row layout (h = N): lane i <= n holds columns 0..h-1 of row i ("low" lanes); rows i >= h
+    // keep their columns h..n-1 in lane i + h + 1 ("high" lanes, up to lane 3N+1 <= 61).  Every lane
+    // holds h entries, 62 of 64 lanes work, and row n carries the right-hand side so that L^{-1} rhs
+    // falls out of the factorisation.  Column j is broadcast through its packed LDS slot.
+    DEV bool chol_solve(T &xout)
+    {
+        constexpr int h = N;
+        static_assert(3 * N + 1 <= 63, "split-row layout needs 3N + 1 <= 63");
+        const bool hi = lane > n;
+        const int myrow = hi ? lane - (h + 1) : lane;       // row index of this lane (may exceed n for idle lanes)
+        T slot[h];
+        {
+            const T *plo = Lc + lane, *phi = Lc + myrow;
+#pragma unroll
+            for (int e = 0; e < h; ++e) slot[e] = hi ? phi[offc(h + e)] : plo[offc(e)];
+        }
+        const T *pbro = Lc + (hi ? h : 0);  // broadcast base: low lanes read L[e][j], high lanes L[h+e][j]
+        bool ok = true;
+        // ---- columns 0..h-1: pivots live in the low lanes ----
+#pragma unroll
+        for (int j = 0; j < h; ++j) {
+            const T d = readlane_(slot[j], j);
+            ok = ok && (d > Real<T>::tiny()) && (d < (T)1e300);
+            const T rinv = rsqrt_(d);
+            T l = slot[j] * rinv;  // L[lane][j] in the low lanes
+            // owners of column j store L[.][j]; everyone else stores into a private dummy word (branch-free)
+            T *dst = (lane >= j && lane <= n) ? Lc + offc(j) + lane : xb + lane;
+            *dst = l;
+            WFENCE();
+            // high lanes fetch L[myrow][j] of their row from the column just written
+            const T lrow = Lc[offc(j) + (hi ? myrow : lane)];
+            const T lhi = hi ? lrow : (T)0;  // multiplier for entries the low lanes have already finalised
+            l = hi ? lrow : l;
+            // next pivot entry first, so that its rsqrt chain overlaps the rest of this rank-1 update
+            if (j + 1 < h) slot[j + 1] -= l * pbro[offc(j) + j + 1];
+            else slot[0] -= lhi * pbro[offc(j) + 0];
+#pragma unroll
+            for (int e = 0; e < h; ++e)
+                if (e != (j + 1 < h ? j + 1 : 0)) slot[e] -= (e > j ? l : lhi) * pbro[offc(j) + e];
+            // pin: the rank-1 update of step j is applied NOW (stops the compiler from sinking the FMAs to
+            // their first use and spilling every broadcast column to scratch)
+#pragma unroll
+            for (int e = 0; e < h; ++e) pin(slot[e]);
+        }
+        // ---- columns h..n-1: pivots live in the high lanes; the low lanes' registers are dead ----
+#pragma unroll
+        for (int e0 = 0; e0 < h; ++e0) {
+            const int j = h + e0;
+            const T d = readlane_(slot[e0], j + h + 1);
+            ok = ok && (d > Real<T>::tiny()) && (d < (T)1e300);
+            const T rinv = rsqrt_(d);
+            const T l = slot[e0] * rinv;
+            T *dst = (hi && myrow >= j && myrow <= n) ? Lc + offc(j) + myrow : xb + lane;
+            *dst = l;
+            WFENCE();
+            if (e0 + 1 < h) slot[e0 + 1] -= l * Lc[offc(j) + h + e0 + 1];
+#pragma unroll
+            for (int e = e0 + 2; e < h; ++e) slot[e] -= l * Lc[offc(j) + h + e];
+#pragma unroll
+            for (int e = 0; e < h; ++e) pin(slot[e]);
+        }
+        if (!ok) return false;
+        WFENCE();
+        // backward substitution L^T x = y: lane j < n owns column j; two passes of h register-resident entries
+        const int jl = lane < n ? lane : 0;
+        const T *pc = Lc + offc_rt(jl);
+        T s = lane < n ? pc[n] : (T)0;
+        const T dinv = lane < n ? (T)1 / pc[jl] : (T)0;
+#pragma unroll
+        for (int e = 0; e < h; ++e) { const T v = pc[h + e]; slot[e] = (h + e > lane && lane < n) ? v : (T)0; }
+#pragma unroll
+        for (int e = h - 1; e >= 0; --e) { const T xi = readlane_(s * dinv, h + e); s -= slot[e] * xi; }
+#pragma unroll
+        for (int e = 0; e < h; ++e) { const T v = pc[e]; slot[e] = (e > lane && lane < n) ? v : (T)0; }
+#pragma unroll
+        for (int e = h - 1; e >= 0; --e) { const T xi = readlane_(s * dinv, e); s -= slot[e] * xi; }
+        xout = s * dinv;
+        WSYNC();
+        return true;
+    }
+
+    DEV bool interior_point(T &Uf)
+    {
+        const T relax = (T)P.relax;
+        T u0[2];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const T ub = j ? (T)P.steer_max : (T)P.a_max;
+            const T d0 = (j ? (T)P.steer_dmax : (T)P.a_dmax) * dtc;
+            const T up = j ? up1 : up0;
+            T lo = fmax(-ub - relax * fmax((T)1, ub), up - d0 - relax * fmax((T)1, d0));
+            T hi = fmin(ub + relax * fmax((T)1, ub), up + d0 + relax * fmax((T)1, d0));
+            if (j == 0) {
+                lo = fmax(lo, ((T)P.v_min - relax * fmax((T)1, fabs((T)P.v_min)) - v0) / dt);
+                hi = fmin(hi, ((T)P.v_max + relax * fmax((T)1, fabs((T)P.v_max)) - v0) / dt);
+            }
+            if (!(lo < hi)) ok = false;
+            const T push = (T)0.25 * (hi - lo);
+            u0[j] = fmin(fmax((T)0, lo + push), hi - push);
+        }
+        const T vm = fmin((T)1, (T)0.25 * ((T)P.v_max - (T)P.v_min)), acap = (T)0.5 * (T)P.a_max;
+        T v = v0 + dt * u0[0];
+        Uf = lane == 0 ? u0[0] : (lane == 1 ? u0[1] : (T)0);
+#pragma unroll
+        for (int k = 1; k < N; ++k) {
+            T a = (T)0;
+            if (v < (T)P.v_min + vm) a = fmin((T)P.v_min + vm - v, acap);
+            else if (v > (T)P.v_max - vm) a = fmax((T)P.v_max - vm - v, -acap);
+            if (lane == 2 * k) Uf = a;
+            v += dt * a;
+        }
+        return ok;
+    }
+
+    DEV void solve(const KIO<T> &io, int b)
+    {
+        const T kappa_eps = 10, kappa_mu = (T)0.2, tau_min = (T)0.99, kappa_sigma = (T)1e10, eta_phi = (T)1e-8, s_max = 100;
+        const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
+        const bool exact = P.hessian == 1;
+        T U, Uf, g = 0, du = 0, rhs, Ut;
+        T bu[NF], bl[NF], au[NF], lu[NF], ll[NF], aut[NF], w[NF];
+        bool fv[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i]); lu[i] = ll[i] = (T)0; }
+        int status = 1, iters = 0;
+        T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0;
+        StageF<T> S;
+        STAMP_DECL
+
+        const bool feas = interior_point(Uf);
+        if (!feas) {
+            status = 2;
+            const T ub = (lane & 1) ? (T)P.steer_max : (T)P.a_max;
+            U = lane < n ? fmin(fmax((lane & 1) ? up1 : up0, -ub), ub) : (T)0;
+        } else {
+            if (P.warm && io.warmU) {
+                const T dw = lane < n ? io.warmU[(size_t)b * n + lane] - Uf : (T)0;
+                forms_apply(Uf, au);
+                forms_apply(dw, aut);
+                T th = 1;
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        if (aut[i] > 0) th = fmin(th, (bu[i] - au[i]) / aut[i]);
+                        if (aut[i] < 0) th = fmin(th, (bl[i] + au[i]) / -aut[i]);
+                    }
+                th = dpp_min(th) * ((T)1 - (T)P.warm_push);
+                U = Uf + th * dw;
+            } else U = Uf;
+            forms_apply(U, au);
+            J = eval(U, S);
+            g = linearize(S, exact);
+            STAMP(0);
+            for (int it = 0; it < P.max_iter; ++it) {
+                asm volatile("" : "+v"(lane));
+                if (it == 0) {
+                    const T gm = dpp_max(fabs(g));
+                    sc = gm > (T)100 ? (T)100 / gm : (T)1;
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) { lu[i] = fv[i] ? mu / (bu[i] - au[i]) : (T)0; ll[i] = fv[i] ? mu / (bl[i] + au[i]) : (T)0; }
+                }
+                ++iters;
+#pragma unroll
+                for (int i = 0; i < NF; ++i) w[i] = lu[i] - ll[i];
+                const T rd = sc * g + forms_applyT(w);
+                T lsum = 0, cm0 = 0, gap = 0;
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        const T cu = (bu[i] - au[i]) * lu[i], cl = (bl[i] + au[i]) * ll[i];
+                        lsum += lu[i] + ll[i]; gap += cu + cl; cm0 = fmax(cm0, fmax(cu, cl));
+                    }
+                const T rdm = dpp_max(fabs(rd));
+                lsum = dpp_sum(lsum); cm0 = dpp_max(cm0); gap = dpp_sum(gap);
+                const T s_d = fmax(s_max, lsum / (T)(2 * nf)) / s_max;
+                const T err0 = fmax(rdm, cm0) / s_d;
+                const T gap_lim = gap_tol * fmax((T)1, fabs(J));
+                if (err0 <= tol && gap / sc <= gap_lim) { status = 0; break; }
+                const T mu_min = fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf));
+                for (;;) {
+                    T cmu = 0;
+#pragma unroll
+                    for (int i = 0; i < NF; ++i)
+                        if (fv[i]) cmu = fmax(cmu, fmax(fabs((bu[i] - au[i]) * lu[i] - mu), fabs((bl[i] + au[i]) * ll[i] - mu)));
+                    cmu = dpp_max(cmu);
+                    if (fmax(rdm, cmu) / s_d <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, mu * sqrt(mu)));
+                    else break;
+                }
+                const T tau = fmax(tau_min, (T)1 - mu);
+                STAMP(2);
+                // rhs = -(sc*g + A^T(mu/s_u - mu/s_l))
+#pragma unroll
+                for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -(mu / (bu[i] - au[i]) - mu / (bl[i] + au[i])) : (T)0;
+                rhs = -sc * g + forms_applyT(w);
+#pragma unroll
+                for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / (bu[i] - au[i]) + ll[i] / (bl[i] + au[i]) : (T)0;
+                stage_form_weights(w);
+                STAMP(6);
+                bool use_exact = exact, factored = false;
+                T reg = 0;
+                for (int attempt = 0; attempt < 14; ++attempt) {
+                    if (attempt > 0) {  // rare: rebuild the linearisation (its registers were released)
+                        J = eval(U, S);
+                        g = linearize(S, use_exact);
+                        stage_form_weights(w);
+                    }
+                    {
+                        acc_t acc[NTT];
+                        condense(use_exact, acc);
+                        STAMP(3);
+                        build_K(acc, sc, reg, rhs);
+                        STAMP(4);
+                    }
+                    if (chol_solve(du)) { factored = true; break; }
+                    if (use_exact) use_exact = false;
+                    else reg = reg == 0 ? (T)1e-8 : reg * (T)100;
+                }
+                STAMP(5);
+                if (!factored) { status = 3; break; }
+                forms_apply(du, aut);
+                T ap = 1, ad = 1, lg = 0;
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        const T su = bu[i] - au[i], sl = bl[i] + au[i], dsu = -aut[i], dsl = aut[i];
+                        const T dlu = (mu - lu[i] * su) / su - lu[i] / su * dsu;
+                        const T dll = (mu - ll[i] * sl) / sl - ll[i] / sl * dsl;
+                        if (dsu < 0) ap = fmin(ap, -tau * su / dsu);
+                        if (dsl < 0) ap = fmin(ap, -tau * sl / dsl);
+                        if (dlu < 0) ad = fmin(ad, -tau * lu[i] / dlu);
+                        if (dll < 0) ad = fmin(ad, -tau * ll[i] / dll);
+                        lg += log(su * sl);
+                    }
+                ap = dpp_min(ap); ad = dpp_min(ad);
+                const T phi0 = sc * J - mu * dpp_sum(lg);
+                const T dphi = dpp_sum(lane < n ? -rhs * du : (T)0);
+                STAMP(8);
+                T alpha = ap, Jt = 0;
+                bool accepted = false;
+                StageF<T> St;
+                for (int l = 0; l < P.max_ls; ++l, alpha *= (T)0.5) {
+                    Ut = U + alpha * du;
+                    Jt = eval(Ut, St);
+                    T lgt = 0;
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < NF; ++i)
+                        if (fv[i]) {
+                            const T a_ = bu[i] - (au[i] + alpha * aut[i]), b_ = bl[i] + (au[i] + alpha * aut[i]);
+                            if (!(a_ > 0) || !(b_ > 0)) ok = false; else lgt += log(a_ * b_);
+                        }
+                    ok = __all(ok);
+                    const T phi = sc * Jt - mu * dpp_sum(lgt);
+                    if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; break; }
+                }
+                STAMP(9);
+                if (!accepted) { status = 3; break; }
+                U = Ut; J = Jt;
+                g = linearize(St, exact);
+                STAMP(1);
+                // dual step recomputed from the pre-step slacks (au still holds A*U_old), then refresh au
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        const T su = bu[i] - au[i], sl = bl[i] + au[i];
+                        lu[i] += ad * ((mu - lu[i] * su) / su + lu[i] / su * aut[i]);
+                        ll[i] += ad * ((mu - ll[i] * sl) / sl - ll[i] / sl * aut[i]);
+                    }
+                forms_apply(U, au);
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        const T su = bu[i] - au[i], sl = bl[i] + au[i];
+                        lu[i] = fmax(fmin(lu[i], kappa_sigma * mu / su), mu / (kappa_sigma * su));
+                        ll[i] = fmax(fmin(ll[i], kappa_sigma * mu / sl), mu / (kappa_sigma * sl));
+                    }
+                STAMP(7);
+            }
+        }
+        STAMP(10);
+        // ---- outputs ----------------------------------------------------------------------------
+        forms_apply(U, au);
+        J = eval(U, S);
+        T viol = -(T)1e30;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+            if (fv[i]) {
+                const int f = lane + 64 * i;
+                viol = fmax(viol, fmax(au[i] - (bu[i] - form_relax(f, true)), -au[i] - (bl[i] - form_relax(f, false))));
+            }
+        viol = dpp_max(viol);
+        if (lane < n) {
+            if (io.outU) io.outU[(size_t)b * n + lane] = U;
+            if (io.warmU) io.warmU[(size_t)b * n + lane] = U;
+            if (lane < 2) io.u0[(size_t)b * 2 + lane] = U;
+        }
+        if (io.outX && lane <= N) {
+            T *o = io.outX + ((size_t)b * (N + 1) + lane) * 4;
+            o[0] = S.x; o[1] = S.y; o[2] = S.psi; o[3] = S.v;
+        }
+        STAMP(11);
+        STAMP_OUT(io.stamps, b);
+        if (lane == 0) {
+            io.status[b] = status;
+            if (io.cost) io.cost[b] = J;
+            if (io.viol) io.viol[b] = viol;
+            if (io.iters) io.iters[b] = iters;
+        }
+    }
+};
+
+template <typename T, int N>
+__global__ __launch_bounds__(64, 3) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N>::lds_elems() * sizeof(T)];
+    const int b = blockIdx.x;
+    if (b >= P.B) return;
+    FastSolver<T, N> sv(P, smem);
+    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
+    sv.solve(io, b);
+}
+
+template <typename T, int N>
+static hipError_t launch_fast_n(const KP &P, const KIO<T> &io, hipStream_t st)
+{
+    hipLaunchKernelGGL((kmpc_solve_fast_kernel<T, N>), dim3(P.B), dim3(64), 0, st, P, io);
+    return hipGetLastError();
+}
+
+// horizons with a compiled fast kernel; everything else runs the generic kernel
+template <typename T> bool kmpc_fast_available(int N) { return N == 8 || N == 20; }  // 3N + 1 <= 63
+template <typename T> hipError_t kmpc_launch_solve_fast(const KP &P, const KIO<T> &io, hipStream_t st)
+{
+    switch (P.N) {
+        case 8: return launch_fast_n<T, 8>(P, io, st);
+        case 20: return launch_fast_n<T, 20>(P, io, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template bool kmpc_fast_available<double>(int);
+template bool kmpc_fast_available<float>(int);
+template hipError_t kmpc_launch_solve_fast<double>(const KP &, const KIO<double> &, hipStream_t);
+template hipError_t kmpc_launch_solve_fast<float>(const KP &, const KIO<float> &, hipStream_t);

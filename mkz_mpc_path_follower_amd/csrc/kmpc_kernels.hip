@@ -22,54 +22,7 @@
 //        f in [0,n) box on u_f | [n, n+R) rate forms, R = 2(N-1) | [n+R, nf) speed prefix sums
 //   stage data: lane k <-> stage / state k (k = 0..N)
 //   H tiles: lower-triangular 16x16 tiles in MFMA C/D layout (col = lane&15, row from Real<T>)
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdint.h>
-
-#include "kmpc_device.h"
-
-#define DEV __device__ __forceinline__
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef float float4_t __attribute__((ext_vector_type(4)));
-
-template <typename T> struct Real;
-template <> struct Real<double> {
-    typedef double4_t acc_t;
-    static DEV acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    // C/D of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
-    static DEV int row_of(int lane, int reg) { return (lane >> 4) + 4 * reg; }
-    static DEV int q_of_row(int rr) { return rr & 3; }
-    static DEV int reg_of_row(int rr) { return rr >> 2; }
-    static DEV void sincos_(double x, double *s, double *c) { sincos(x, s, c); }
-    static DEV double eps() { return 2.220446049250313e-16; }
-    static DEV double tiny() { return 1e-300; }
-};
-template <> struct Real<float> {
-    typedef float4_t acc_t;
-    static DEV acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    // C/D of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4*(lane>>4) + reg
-    static DEV int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
-    static DEV int q_of_row(int rr) { return rr >> 2; }
-    static DEV int reg_of_row(int rr) { return rr & 3; }
-    static DEV void sincos_(float x, float *s, float *c) { sincosf(x, s, c); }
-    static DEV float eps() { return 1.1920929e-07f; }
-    static DEV float tiny() { return 1e-30f; }
-};
-
-// ---- wave primitives (64 lanes, one wave per workgroup) -------------------------------------
-template <typename T> DEV T wave_sum(T x) { for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o); return x; }
-template <typename T> DEV T wave_max(T x) { for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o)); return x; }
-template <typename T> DEV T wave_min(T x) { for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o)); return x; }
-template <typename T> DEV T scan_prefix(T x, int lane) {  // inclusive, lane 0 -> 63
-    for (int d = 1; d < 64; d <<= 1) { T t = __shfl_up(x, d); if (lane >= d) x += t; }
-    return x;
-}
-template <typename T> DEV T scan_suffix(T x, int lane) {  // inclusive, lane 63 -> 0
-    for (int d = 1; d < 64; d <<= 1) { T t = __shfl_down(x, d); if (lane + d < 64) x += t; }
-    return x;
-}
-#define WSYNC() __syncthreads()
+#include "kmpc_common.h"
 
 // per-lane stage record: lane k holds state k (k = 0..N) and input k (k < N)
 template <typename T> struct Stage {
@@ -507,6 +460,7 @@ template <typename T, int NT> struct Solver {
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, err0 = 0;
         Stage<T> S, St;
         acc_t acc[NTT];
+        STAMP_DECL
 
         const bool feas = interior_point(Uf);
         if (!feas) {
@@ -544,8 +498,10 @@ template <typename T, int NT> struct Solver {
             for (int i = 0; i < NF; ++i) { su[i] = bu[i] - au[i]; sl[i] = bl[i] + au[i]; }
             J = eval(U, S);
 
+            STAMP(0);
             for (int it = 0; it < P.max_iter; ++it) {
                 linearize(S, exact, g);
+                STAMP(1);
                 if (it == 0) {
                     T gm = 0;
 #pragma unroll
@@ -590,6 +546,7 @@ template <typename T, int NT> struct Solver {
                     else break;
                 }
                 const T tau = fmax(tau_min, (T)1 - mu);
+                STAMP(2);
                 // factor K = sc*H + A^T Sigma A
 #pragma unroll
                 for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / su[i] + ll[i] / sl[i] : (T)0;
@@ -598,9 +555,13 @@ template <typename T, int NT> struct Solver {
                 bool factored = false;
                 for (int attempt = 0; attempt < 14; ++attempt) {
                     if (attempt <= 1) condense(use_exact, acc);
+                    STAMP(3);
                     stage_form_weights(w);
                     build_K(acc, sc, reg);
-                    if (cholesky()) { factored = true; break; }
+                    STAMP(4);
+                    const bool okc = cholesky();
+                    STAMP(5);
+                    if (okc) { factored = true; break; }
                     if (use_exact) use_exact = false;            // drop the second-order term first
                     else reg = reg == 0 ? (T)1e-8 : reg * (T)100;  // then delta_w escalation
                 }
@@ -613,7 +574,9 @@ template <typename T, int NT> struct Solver {
                 forms_applyT_add(w, rhs);
 #pragma unroll
                 for (int i = 0; i < NV; ++i) du[i] = rhs[i];
+                STAMP(6);
                 chol_solve(du);
+                STAMP(7);
                 forms_apply(du, aut);
                 T ap = 1, ad = 1;
 #pragma unroll
@@ -637,6 +600,7 @@ template <typename T, int NT> struct Solver {
                 for (int i = 0; i < NV; ++i) dphi -= rhs[i] * du[i];
                 const T phi0 = sc * J - mu * wave_sum(lg);
                 dphi = wave_sum(dphi);
+                STAMP(8);
                 T alpha = ap, Jt = 0;
                 bool accepted = false;
                 for (int l = 0; l < P.max_ls; ++l, alpha *= (T)0.5) {
@@ -656,6 +620,7 @@ template <typename T, int NT> struct Solver {
                     const T phi = sc * Jt - mu * wave_sum(lgt);
                     if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; break; }
                 }
+                STAMP(9);
                 if (!accepted) { status = 3; break; }
 #pragma unroll
                 for (int i = 0; i < NV; ++i) U[i] = Ut[i];
@@ -670,6 +635,7 @@ template <typename T, int NT> struct Solver {
                     }
             }
         }
+        STAMP(10);
         // ---- outputs ----------------------------------------------------------------------------
         forms_apply(U, au);
         T viol = -(T)1e30;
@@ -699,6 +665,8 @@ template <typename T, int NT> struct Solver {
             T *o = io.outX + ((size_t)b * (N + 1) + lane) * 4;
             o[0] = S.x; o[1] = S.y; o[2] = S.psi; o[3] = S.v;
         }
+        STAMP(11);
+        STAMP_OUT(io.stamps, b);
         if (lane == 0) {
             io.status[b] = status;
             if (io.cost) io.cost[b] = J;
