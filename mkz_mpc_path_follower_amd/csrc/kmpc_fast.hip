@@ -1,17 +1,22 @@
-// kmpc_fast.hip -- compile-time-horizon solver kernel for gfx950 (n + 1 = 2N + 1 <= 64 lanes).
+// kmpc_fast.hip -- compile-time-horizon solver kernel for gfx950 (2N + 1 <= 64 lanes, N % 4 == 0).
 //
 // Same algorithm and same results as the generic kernel in kmpc_kernels.hip (one wavefront per
-// problem; see the header there), restructured so that a lone wave is not stalled on LDS /
-// ds_bpermute round trips and so that 4 waves fit per SIMD:
-//   * every loop over stages / columns is fully unrolled: register files are indexed statically,
-//     per-stage scalars are broadcast with v_readlane (constant lane), no LDS staging of them;
-//   * scans and reductions run on DPP (row_shr / row_shl / row_bcast), not ds_bpermute;
-//   * the condensed Hessian stays in the MFMA accumulators until it is written ONCE, with the
+// problem; see the header there).  What this kernel is organised around, in order of importance
+// (measured on MI355X, profiles/):
+//   * INSTRUCTION FOOTPRINT.  A fully unrolled version of this kernel (109 KB of code) ran at
+//     ~1 byte of instructions per cycle per wave with no benefit from 4 waves per SIMD: it was
+//     instruction-fetch bound (the I-cache is 64 KB per CU pair).  So every loop over stages /
+//     columns is ROLLED, register arrays are indexed statically by shifting them one slot per
+//     step, and the roll-out, the linearisation and the factorisation each have ONE call site
+//     (the iteration is a small state machine: a line-search trial and the next iterate's
+//     evaluation are the same code).
+//   * no ds_bpermute / LDS round trips for scans and reductions: DPP row_shr / row_shl / row_bcast;
+//   * the condensed Hessian stays in the MFMA accumulators until it is written once, with the
 //     barrier terms, into a packed column-major LDS image (n(n+3)/2 words, 6.9 KB at N = 20);
-//   * Cholesky keeps row i of K in the registers of lane i; column j is broadcast through its
-//     packed LDS slot (uniform-address reads); the right-hand side rides along as row n, so the
-//     forward substitution is free; the backward substitution chains v_readlane + FMA on
-//     register-resident columns.
+//     the stage second-derivative rows are rank-1 MFMAs into the same accumulators;
+//   * Cholesky keeps the active part of row i in the registers of lane i (N entries), in three
+//     rolled phases: columns 0..N-1, Schur update of the trailing block, columns N..2N-1.  The
+//     right-hand side rides along as row n, so the forward substitution is free.
 #include "kmpc_common.h"
 
 #define WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
@@ -88,7 +93,7 @@ template <typename T, int N> struct FastSolver {
     static constexpr int SROWS = (N + 1 + 15) / 16;  // 16-lane rows that carry stage data
     static constexpr int NROWS = (n + 1 + 15) / 16;  // rows that carry n-vector data
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
-    static_assert(n + 1 <= 64, "fast kernel needs 2N + 1 <= 64");
+    static_assert(n + 1 <= 64 && n % 8 == 0, "fast kernel needs 2N + 1 <= 64 and N % 4 == 0");
     typedef typename Real<T>::acc_t acc_t;
     static_assert(LIN_STRIDE * (N + 1) <= LC, "stage scalars must fit in the K image");
     static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64; }
@@ -302,7 +307,7 @@ template <typename T, int N> struct FastSolver {
             T *w0 = k <= N ? q : dmy;
             w0[0] = A02; w0[1] = A03;
             if (k <= N) { q[2] = A12; q[3] = A13; q[4] = A23; q[5] = Bdx; q[6] = Bdy; q[7] = Bdp;
-                          q[8] = mpp; q[9] = mpv; q[10] = mpd; q[11] = mvd; q[12] = mdd; }
+                          q[8] = mpp; q[9] = mpv; q[10] = mpd; q[11] = mvd; q[12] = mdd; q[13] = (T)0; }
         }
         WSYNC();
         const T g = lane < n ? xb[lane] : (T)0;
@@ -310,7 +315,7 @@ template <typename T, int N> struct FastSolver {
         return g;
     }
 
-    // condensing on the matrix cores, stage loop fully unrolled, stage scalars by v_readlane
+    // condensing on the matrix cores; ROLLED stage loop (runtime s), static register indices
     DEV void condense(bool exact, acc_t (&acc)[NTT])
     {
         const int kk = lane >> 4, c = lane & 15;
@@ -319,33 +324,37 @@ template <typename T, int N> struct FastSolver {
         T own[NT], gps[NT], gv[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) own[t] = gps[t] = gv[t] = (T)0;
-#pragma unroll
+        // per-lane word offsets into a stage record (word 13 is a stored zero): each lane fetches the
+        // coefficient ITS row needs, so no selects and one batch of independent ds_reads per stage
+        const int iA = kk == 0 ? 0 : (kk == 1 ? 2 : 13);                  // A02 | A12 | 0   | 0
+        const int iB = kk == 0 ? 1 : (kk == 1 ? 3 : (kk == 2 ? 4 : 13));  // A03 | A13 | A23 | 0
+        const int iO = kk == 0 ? 5 : (kk == 1 ? 6 : (kk == 2 ? 7 : 13));  // Bdx | Bdy | Bdp | 0
+        const int iD = kk == 2 ? 8 : 13;                                  // 0   | 0   | mpp | 0
+        const int iE = kk >= 2 ? 9 : 13;                                  // 0   | 0   | mpv | mpv
+        const T o0 = kk == 3 ? dt : (T)0;
+        const T dbase = kk == 0 ? (T)2 * Cx : (kk == 1 ? (T)2 * Cy : (kk == 2 ? (T)2 * Cp : (T)0));
+#pragma nounroll
         for (int s = 0; s <= N; ++s) {
+            const T *qs = Lc + LIN_STRIDE * (s < N ? s : N - 1);  // second-order scalars of stage s (unused at s = N)
+            const T ex_ = (exact && s < N) ? (T)1 : (T)0;
+            const T mppl = qs[iD], mpvl = qs[iE], mpd = ex_ * qs[10], mvd = ex_ * qs[11], mdd = ex_ * qs[12];
             if (s >= 1) {
-                const int sp = s - 1;
-                const T *q = Lc + LIN_STRIDE * sp;  // uniform-address LDS reads
-                const T A02 = q[0], A03 = q[1], A12 = q[2], A13 = q[3], A23 = q[4], Bdx = q[5], Bdy = q[6], Bdp = q[7];
-                const T cA = kk == 0 ? A02 : (kk == 1 ? A12 : (T)0);
-                const T cB = kk == 0 ? A03 : (kk == 1 ? A13 : (kk == 2 ? A23 : (T)0));
-                const T bo = kk == 0 ? Bdx : (kk == 1 ? Bdy : (kk == 2 ? Bdp : (T)0));
-                const int col0 = 2 * sp;
+                const T *q = Lc + LIN_STRIDE * (s - 1);
+                const T cA = q[iA], cB = q[iB], bo = q[iO], A23 = q[4], Bdp = q[7];
+                const int col0 = 2 * (s - 1), t0 = col0 >> 4;
+                const bool m0 = c == (col0 & 15), m1 = c == (col0 & 15) + 1;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (16 * t < col0) {  // tiles that already hold columns
-                        own[t] += cA * gps[t] + cB * gv[t];
-                        gps[t] += A23 * gv[t];
-                    }
-                    if (t == (col0 >> 4)) {
-                        const int col = 16 * t + c;
-                        if (col == col0) { own[t] = kk == 3 ? dt : (T)0; gps[t] = (T)0; gv[t] = dt; }
-                        if (col == col0 + 1) { own[t] = bo; gps[t] = Bdp; gv[t] = (T)0; }
+                for (int t = 0; t < NT; ++t) {  // G_s = [A_{s-1} G_{s-1} | B_{s-1}]  (columns not yet present are zero)
+                    own[t] += cA * gps[t] + cB * gv[t];
+                    gps[t] += A23 * gv[t];
+                    if (t == t0) {
+                        own[t] = m0 ? o0 : (m1 ? bo : own[t]);
+                        gps[t] = m0 ? (T)0 : (m1 ? Bdp : gps[t]);
+                        gv[t] = m0 ? dt : (m1 ? (T)0 : gv[t]);
                     }
                 }
-                const T mpp = (exact && s < N) ? Lc[LIN_STRIDE * s + 8] : (T)0;
-                const T mpv = (exact && s < N) ? Lc[LIN_STRIDE * s + 9] : (T)0;
-                const T Cvs = s <= N - 1 ? Cv : (T)0;
-                const T dco = kk == 0 ? (T)2 * Cx : (kk == 1 ? (T)2 * Cy : (kk == 2 ? (T)2 * Cp + mpp : (T)2 * Cvs));
-                const T oco = kk >= 2 ? mpv : (T)0;
+                const T dco = dbase + ex_ * mppl + ((kk == 3 && s <= N - 1) ? (T)2 * Cv : (T)0);
+                const T oco = ex_ * mpvl;
                 T bop[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bop[t] = dco * own[t] + oco * (kk == 2 ? gv[t] : gps[t]);
@@ -357,22 +366,23 @@ template <typename T, int N> struct FastSolver {
                             acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[ti * (ti + 1) / 2 + tj]);
                     }
             }
-            if (s < N) {  // row 2s+1 (d_f of stage s) of the second-order term
-                const T mpd = exact ? Lc[LIN_STRIDE * s + 10] : (T)0, mvd = exact ? Lc[LIN_STRIDE * s + 11] : (T)0,
-                        mdd = exact ? Lc[LIN_STRIDE * s + 12] : (T)0;
+            if (exact && s < N) {
+                // row rho = 2s+1 (d_f of stage s) of the second-order term as a rank-1 MFMA:
+                // A = e_rho (k-slot 0), B = mpd*G_psi + mvd*G_v (+ mdd on the diagonal)
                 const int rho = 2 * s + 1, rt = rho >> 4, rr = rho & 15;
-                const bool mine = kk == Real<T>::q_of_row(rr);
-                const int reg = Real<T>::reg_of_row(rr);
+                const T aop = (kk == 0 && c == rr) ? (T)1 : (T)0;
 #pragma unroll
-                for (int tj = 0; tj < NT; ++tj)
-                    if (tj <= rt) {
-                        T val = mpd * gps[tj] + mvd * gv[tj];
-                        if (tj == rt && c == rr) val += mdd;
-                        if (!mine) val = (T)0;
-                        acc[rt * (rt + 1) / 2 + tj][reg] += val;
+                for (int ti = 0; ti < NT; ++ti)
+                    if (ti == rt) {
+#pragma unroll
+                        for (int tj = 0; tj <= ti; ++tj) {
+                            T b = mpd * gps[tj] + mvd * gv[tj];
+                            if (tj == ti) b += (c == rr) ? mdd : (T)0;
+                            b = kk == 0 ? b : (T)0;
+                            acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(aop, b, acc[ti * (ti + 1) / 2 + tj]);
+                        }
                     }
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the unrolled stages from being interleaved (register pressure)
         }
     }
 
@@ -422,84 +432,75 @@ template <typename T, int N> struct FastSolver {
         WSYNC();
     }
 
+    // One rolled elimination sweep over columns [j0, j1): lane i holds the live part of row i in
+    // slot[] with the CURRENT pivot column at slot[0] (the array shifts one place per step, so all
+    // register indices are static).  LEN = number of trailing entries that still matter.
+    template <int LEN> DEV void chol_sweep(T (&slot)[N], int j0, int j1, bool &ok)
+    {
+#pragma nounroll
+        for (int j = j0; j < j1; ++j) {
+            const T d = readlane_(slot[0], j);
+            ok = ok && (d > Real<T>::tiny()) && (d < (T)1e300);
+            const T rinv = rsqrt_(d);
+            const T l = slot[0] * rinv;  // L[lane][j] (lanes < j hold garbage that nothing reads)
+            T *dst = (lane >= j && lane <= n) ? Lc + offc_rt(j) + lane : xb + lane;  // branch-free: others hit a dummy word
+            *dst = l;                     // kept for the Schur phase and the backward substitution
+            // rank-1 update; the multiplier L[j+1+p][j] is lane (j+1+p)'s own l: v_readlane, no LDS round trip
+#pragma unroll
+            for (int p = 0; p < LEN; ++p) {
+                const int src = j + 1 + p;
+                slot[p] = fma(-l, readlane_(l, src < 64 ? src : 63), slot[p + 1 < N ? p + 1 : N - 1]);
+            }
+        }
+    }
+
     // In-register Cholesky of the packed image + both substitutions; x (lane j) = K^{-1} rhs.
-    // Split-row layout (h = N): lane i <= n holds columns 0..h-1 of row i ("low" lanes); rows i >= h
-    // keep their columns h..n-1 in lane i + h + 1 ("high" lanes, up to lane 3N+1 <= 61).  Every lane
-    // holds h entries, 62 of 64 lanes work, and row n carries the right-hand side so that L^{-1} rhs
-    // falls out of the factorisation.  Column j is broadcast through its packed LDS slot.
+    // Rows (and the rhs as row n) live one per lane.  Three rolled phases with h = N:
+    //   1. columns 0..h-1      : every row holds its entries of columns 0..h-1
+    //   2. Schur update        : rows h..n load their columns h..n-1 and subtract L21 L21^T
+    //   3. columns h..n-1      : same sweep as phase 1
+    // Column j of L is stored into its packed LDS slot as soon as it is final; the substitution
+    // L^{-1} rhs falls out as row n.
     DEV bool chol_solve(T &xout)
     {
         constexpr int h = N;
-        static_assert(3 * N + 1 <= 63, "split-row layout needs 3N + 1 <= 63");
-        const bool hi = lane > n;
-        const int myrow = hi ? lane - (h + 1) : lane;       // row index of this lane (may exceed n for idle lanes)
+        static_assert(N % 4 == 0 && N >= 8, "rolled Cholesky assumes N % 4 == 0");
+        constexpr int L1 = h - 1, L2 = h / 2 - 1;
         T slot[h];
-        {
-            const T *plo = Lc + lane, *phi = Lc + myrow;
-#pragma unroll
-            for (int e = 0; e < h; ++e) slot[e] = hi ? phi[offc(h + e)] : plo[offc(e)];
-        }
-        const T *pbro = Lc + (hi ? h : 0);  // broadcast base: low lanes read L[e][j], high lanes L[h+e][j]
         bool ok = true;
-        // ---- columns 0..h-1: pivots live in the low lanes ----
 #pragma unroll
-        for (int j = 0; j < h; ++j) {
-            const T d = readlane_(slot[j], j);
-            ok = ok && (d > Real<T>::tiny()) && (d < (T)1e300);
-            const T rinv = rsqrt_(d);
-            T l = slot[j] * rinv;  // L[lane][j] in the low lanes
-            // owners of column j store L[.][j]; everyone else stores into a private dummy word (branch-free)
-            T *dst = (lane >= j && lane <= n) ? Lc + offc(j) + lane : xb + lane;
-            *dst = l;
-            WFENCE();
-            // high lanes fetch L[myrow][j] of their row from the column just written
-            const T lrow = Lc[offc(j) + (hi ? myrow : lane)];
-            const T lhi = hi ? lrow : (T)0;  // multiplier for entries the low lanes have already finalised
-            l = hi ? lrow : l;
-            // next pivot entry first, so that its rsqrt chain overlaps the rest of this rank-1 update
-            if (j + 1 < h) slot[j + 1] -= l * pbro[offc(j) + j + 1];
-            else slot[0] -= lhi * pbro[offc(j) + 0];
+        for (int e = 0; e < h; ++e) slot[e] = Lc[offc(e) + lane];
+        chol_sweep<L1>(slot, 0, h / 2, ok);
+        chol_sweep<L2>(slot, h / 2, h, ok);
+        WFENCE();
 #pragma unroll
-            for (int e = 0; e < h; ++e)
-                if (e != (j + 1 < h ? j + 1 : 0)) slot[e] -= (e > j ? l : lhi) * pbro[offc(j) + e];
-            // pin: the rank-1 update of step j is applied NOW (stops the compiler from sinking the FMAs to
-            // their first use and spilling every broadcast column to scratch)
+        for (int e = 0; e < h; ++e) slot[e] = Lc[offc(h + e) + lane];
+        T li = Lc[offc_rt(0) + lane];
+#pragma nounroll
+        for (int j = 0; j < h; ++j) {  // trailing block -= L21 L21^T, one column of L21 per pass
+            const T lc = li;
+            li = Lc[offc_rt(j + 1 < h ? j + 1 : j) + lane];  // prefetch the next column's entry of this row
 #pragma unroll
-            for (int e = 0; e < h; ++e) pin(slot[e]);
+            for (int e = 0; e < h; ++e) slot[e] = fma(-lc, readlane_(lc, h + e), slot[e]);  // L[h+e][j] is lane h+e's lc
         }
-        // ---- columns h..n-1: pivots live in the high lanes; the low lanes' registers are dead ----
-#pragma unroll
-        for (int e0 = 0; e0 < h; ++e0) {
-            const int j = h + e0;
-            const T d = readlane_(slot[e0], j + h + 1);
-            ok = ok && (d > Real<T>::tiny()) && (d < (T)1e300);
-            const T rinv = rsqrt_(d);
-            const T l = slot[e0] * rinv;
-            T *dst = (hi && myrow >= j && myrow <= n) ? Lc + offc(j) + myrow : xb + lane;
-            *dst = l;
-            WFENCE();
-            if (e0 + 1 < h) slot[e0 + 1] -= l * Lc[offc(j) + h + e0 + 1];
-#pragma unroll
-            for (int e = e0 + 2; e < h; ++e) slot[e] -= l * Lc[offc(j) + h + e];
-#pragma unroll
-            for (int e = 0; e < h; ++e) pin(slot[e]);
-        }
+        chol_sweep<L1>(slot, h, h + h / 2, ok);
+        chol_sweep<L2>(slot, h + h / 2, n, ok);
         if (!ok) return false;
         WFENCE();
-        // backward substitution L^T x = y: lane j < n owns column j; two passes of h register-resident entries
+        // backward substitution L^T x = y: lane j < n owns column j; blocks of 8 register-resident entries
         const int jl = lane < n ? lane : 0;
         const T *pc = Lc + offc_rt(jl);
-        T s = lane < n ? pc[n] : (T)0;
+        T sacc = lane < n ? pc[n] : (T)0;
         const T dinv = lane < n ? (T)1 / pc[jl] : (T)0;
+#pragma nounroll
+        for (int blk = n / 8 - 1; blk >= 0; --blk) {
+            T cv[8];
 #pragma unroll
-        for (int e = 0; e < h; ++e) { const T v = pc[h + e]; slot[e] = (h + e > lane && lane < n) ? v : (T)0; }
+            for (int u = 0; u < 8; ++u) { const int i = 8 * blk + u; const T v = pc[i]; cv[u] = (i > lane && lane < n) ? v : (T)0; }
 #pragma unroll
-        for (int e = h - 1; e >= 0; --e) { const T xi = readlane_(s * dinv, h + e); s -= slot[e] * xi; }
-#pragma unroll
-        for (int e = 0; e < h; ++e) { const T v = pc[e]; slot[e] = (e > lane && lane < n) ? v : (T)0; }
-#pragma unroll
-        for (int e = h - 1; e >= 0; --e) { const T xi = readlane_(s * dinv, e); s -= slot[e] * xi; }
-        xout = s * dinv;
+            for (int u = 7; u >= 0; --u) { const T xi = readlane_(sacc * dinv, 8 * blk + u); sacc = fma(-cv[u], xi, sacc); }
+        }
+        xout = sacc * dinv;
         WSYNC();
         return true;
     }
@@ -538,28 +539,37 @@ template <typename T, int N> struct FastSolver {
         return ok;
     }
 
+    // The whole solve as one small state machine (one call site per phase -- see the file header):
+    //   TRIAL : Ut was just evaluated; Armijo-test it (the very first point and refactor passes skip the test)
+    //   after acceptance: duals, linearise, optimality test, mu, condense, factor, direction, first trial
+    //   FINAL : last evaluation, for the predicted states, then exit
     DEV void solve(const KIO<T> &io, int b)
     {
         const T kappa_eps = 10, kappa_mu = (T)0.2, tau_min = (T)0.99, kappa_sigma = (T)1e10, eta_phi = (T)1e-8, s_max = 100;
         const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
         const bool exact = P.hessian == 1;
-        T U, Uf, g = 0, du = 0, rhs, Ut;
+        T U, Ut, g = 0, du = 0, rhs = 0;
         T bu[NF], bl[NF], au[NF], lu[NF], ll[NF], aut[NF], w[NF];
         bool fv[NF];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i]); lu[i] = ll[i] = (T)0; }
-        int status = 1, iters = 0;
-        T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0;
-        StageF<T> S;
+        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i]); lu[i] = ll[i] = au[i] = aut[i] = (T)0; }
+        int status = 1, iters = 0, ls = 0, attempt = 0;
+        T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, Jt = 0, alpha = 0, ad = 0, phi0 = 0, dphi = 0, reg = 0;
+        bool use_exact = exact;
+        enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3 };
+        int mode = FIRST;
+        StageF<T> St;
         STAMP_DECL
 
-        const bool feas = interior_point(Uf);
-        if (!feas) {
-            status = 2;
-            const T ub = (lane & 1) ? (T)P.steer_max : (T)P.a_max;
-            U = lane < n ? fmin(fmax((lane & 1) ? up1 : up0, -ub), ub) : (T)0;
-        } else {
-            if (P.warm && io.warmU) {
+        {
+            T Uf;
+            const bool feas = interior_point(Uf);
+            if (!feas) {
+                status = 2;
+                const T ub = (lane & 1) ? (T)P.steer_max : (T)P.a_max;
+                U = lane < n ? fmin(fmax((lane & 1) ? up1 : up0, -ub), ub) : (T)0;
+                mode = FINAL;
+            } else if (P.warm && io.warmU) {
                 const T dw = lane < n ? io.warmU[(size_t)b * n + lane] - Uf : (T)0;
                 forms_apply(Uf, au);
                 forms_apply(dw, aut);
@@ -573,19 +583,63 @@ template <typename T, int N> struct FastSolver {
                 th = dpp_min(th) * ((T)1 - (T)P.warm_push);
                 U = Uf + th * dw;
             } else U = Uf;
-            forms_apply(U, au);
-            J = eval(U, S);
-            g = linearize(S, exact);
-            STAMP(0);
-            for (int it = 0; it < P.max_iter; ++it) {
-                asm volatile("" : "+v"(lane));
-                if (it == 0) {
+        }
+        Ut = U;
+        STAMP(0);
+#pragma nounroll
+        for (;;) {
+            asm volatile("" : "+v"(lane));
+            Jt = eval(Ut, St);
+            STAMP(9);
+            if (mode == FINAL) break;
+            if (mode == TRIAL) {
+                T lgt = 0;
+                bool okp = true;
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        const T a_ = bu[i] - (au[i] + alpha * aut[i]), b_ = bl[i] + (au[i] + alpha * aut[i]);
+                        if (!(a_ > 0) || !(b_ > 0)) okp = false; else lgt += log(a_ * b_);
+                    }
+                okp = __all(okp);
+                const T phi = sc * Jt - mu * dpp_sum(lgt);
+                if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi)) {
+                    if (++ls >= P.max_ls) { status = 3; mode = FINAL; Ut = U; continue; }
+                    alpha *= (T)0.5;
+                    Ut = U + alpha * du;
+                    continue;
+                }
+                // accepted: dual step from the pre-step slacks (au still holds A*U_old)
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        const T su = bu[i] - au[i], sl = bl[i] + au[i];
+                        lu[i] += ad * ((mu - lu[i] * su) / su + lu[i] / su * aut[i]);
+                        ll[i] += ad * ((mu - ll[i] * sl) / sl - ll[i] / sl * aut[i]);
+                    }
+            }
+            U = Ut; J = Jt;
+            g = linearize(St, use_exact);
+            STAMP(1);
+            if (mode != REFACTOR) {
+                forms_apply(U, au);
+                if (mode == FIRST) {
                     const T gm = dpp_max(fabs(g));
-                    sc = gm > (T)100 ? (T)100 / gm : (T)1;
+                    sc = gm > (T)100 ? (T)100 / gm : (T)1;  // Ipopt nlp_scaling_max_gradient
 #pragma unroll
                     for (int i = 0; i < NF; ++i) { lu[i] = fv[i] ? mu / (bu[i] - au[i]) : (T)0; ll[i] = fv[i] ? mu / (bl[i] + au[i]) : (T)0; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NF; ++i)
+                        if (fv[i]) {
+                            const T su = bu[i] - au[i], sl = bl[i] + au[i];
+                            lu[i] = fmax(fmin(lu[i], kappa_sigma * mu / su), mu / (kappa_sigma * su));
+                            ll[i] = fmax(fmin(ll[i], kappa_sigma * mu / sl), mu / (kappa_sigma * sl));
+                        }
                 }
+                if (iters >= P.max_iter) { mode = FINAL; Ut = U; continue; }  // status stays ITERATION_LIMIT
                 ++iters;
+                // optimality error (Ipopt's scaled test + unscaled duality-gap bound)
 #pragma unroll
                 for (int i = 0; i < NF; ++i) w[i] = lu[i] - ll[i];
                 const T rd = sc * g + forms_applyT(w);
@@ -601,9 +655,10 @@ template <typename T, int N> struct FastSolver {
                 const T s_d = fmax(s_max, lsum / (T)(2 * nf)) / s_max;
                 const T err0 = fmax(rdm, cm0) / s_d;
                 const T gap_lim = gap_tol * fmax((T)1, fabs(J));
-                if (err0 <= tol && gap / sc <= gap_lim) { status = 0; break; }
+                if (err0 <= tol && gap / sc <= gap_lim) { status = 0; mode = FINAL; Ut = U; continue; }
                 const T mu_min = fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf));
-                for (;;) {
+#pragma nounroll
+                for (;;) {  // monotone barrier update
                     T cmu = 0;
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
@@ -612,101 +667,61 @@ template <typename T, int N> struct FastSolver {
                     if (fmax(rdm, cmu) / s_d <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, mu * sqrt(mu)));
                     else break;
                 }
-                const T tau = fmax(tau_min, (T)1 - mu);
+                use_exact = exact; reg = 0; attempt = 0;
                 STAMP(2);
-                // rhs = -(sc*g + A^T(mu/s_u - mu/s_l))
-#pragma unroll
-                for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -(mu / (bu[i] - au[i]) - mu / (bl[i] + au[i])) : (T)0;
-                rhs = -sc * g + forms_applyT(w);
-#pragma unroll
-                for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / (bu[i] - au[i]) + ll[i] / (bl[i] + au[i]) : (T)0;
-                stage_form_weights(w);
-                STAMP(6);
-                bool use_exact = exact, factored = false;
-                T reg = 0;
-                for (int attempt = 0; attempt < 14; ++attempt) {
-                    if (attempt > 0) {  // rare: rebuild the linearisation (its registers were released)
-                        J = eval(U, S);
-                        g = linearize(S, use_exact);
-                        stage_form_weights(w);
-                    }
-                    {
-                        acc_t acc[NTT];
-                        condense(use_exact, acc);
-                        STAMP(3);
-                        build_K(acc, sc, reg, rhs);
-                        STAMP(4);
-                    }
-                    if (chol_solve(du)) { factored = true; break; }
-                    if (use_exact) use_exact = false;
-                    else reg = reg == 0 ? (T)1e-8 : reg * (T)100;
-                }
-                STAMP(5);
-                if (!factored) { status = 3; break; }
-                forms_apply(du, aut);
-                T ap = 1, ad = 1, lg = 0;
-#pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        const T su = bu[i] - au[i], sl = bl[i] + au[i], dsu = -aut[i], dsl = aut[i];
-                        const T dlu = (mu - lu[i] * su) / su - lu[i] / su * dsu;
-                        const T dll = (mu - ll[i] * sl) / sl - ll[i] / sl * dsl;
-                        if (dsu < 0) ap = fmin(ap, -tau * su / dsu);
-                        if (dsl < 0) ap = fmin(ap, -tau * sl / dsl);
-                        if (dlu < 0) ad = fmin(ad, -tau * lu[i] / dlu);
-                        if (dll < 0) ad = fmin(ad, -tau * ll[i] / dll);
-                        lg += log(su * sl);
-                    }
-                ap = dpp_min(ap); ad = dpp_min(ad);
-                const T phi0 = sc * J - mu * dpp_sum(lg);
-                const T dphi = dpp_sum(lane < n ? -rhs * du : (T)0);
-                STAMP(8);
-                T alpha = ap, Jt = 0;
-                bool accepted = false;
-                StageF<T> St;
-                for (int l = 0; l < P.max_ls; ++l, alpha *= (T)0.5) {
-                    Ut = U + alpha * du;
-                    Jt = eval(Ut, St);
-                    T lgt = 0;
-                    bool ok = true;
-#pragma unroll
-                    for (int i = 0; i < NF; ++i)
-                        if (fv[i]) {
-                            const T a_ = bu[i] - (au[i] + alpha * aut[i]), b_ = bl[i] + (au[i] + alpha * aut[i]);
-                            if (!(a_ > 0) || !(b_ > 0)) ok = false; else lgt += log(a_ * b_);
-                        }
-                    ok = __all(ok);
-                    const T phi = sc * Jt - mu * dpp_sum(lgt);
-                    if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; break; }
-                }
-                STAMP(9);
-                if (!accepted) { status = 3; break; }
-                U = Ut; J = Jt;
-                g = linearize(St, exact);
-                STAMP(1);
-                // dual step recomputed from the pre-step slacks (au still holds A*U_old), then refresh au
-#pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        const T su = bu[i] - au[i], sl = bl[i] + au[i];
-                        lu[i] += ad * ((mu - lu[i] * su) / su + lu[i] / su * aut[i]);
-                        ll[i] += ad * ((mu - ll[i] * sl) / sl - ll[i] / sl * aut[i]);
-                    }
-                forms_apply(U, au);
-#pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        const T su = bu[i] - au[i], sl = bl[i] + au[i];
-                        lu[i] = fmax(fmin(lu[i], kappa_sigma * mu / su), mu / (kappa_sigma * su));
-                        ll[i] = fmax(fmin(ll[i], kappa_sigma * mu / sl), mu / (kappa_sigma * sl));
-                    }
-                STAMP(7);
             }
+            // rhs = -(sc*g + A^T(mu/s_u - mu/s_l)); form weights for A^T Sigma A
+#pragma unroll
+            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -(mu / (bu[i] - au[i]) - mu / (bl[i] + au[i])) : (T)0;
+            rhs = -sc * g + forms_applyT(w);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / (bu[i] - au[i]) + ll[i] / (bl[i] + au[i]) : (T)0;
+            stage_form_weights(w);
+            STAMP(6);
+            bool factored;
+            {
+                acc_t acc[NTT];
+                condense(use_exact, acc);
+                STAMP(3);
+                build_K(acc, sc, reg, rhs);
+                STAMP(4);
+            }
+            factored = chol_solve(du);
+            STAMP(5);
+            if (!factored) {
+                if (++attempt >= 14) { status = 3; mode = FINAL; Ut = U; continue; }
+                if (use_exact) { use_exact = false; mode = REFACTOR; Ut = U; continue; }  // drop the second-order term first
+                reg = reg == 0 ? (T)1e-8 : reg * (T)100;                                   // then delta_w escalation
+                mode = REFACTOR; Ut = U;
+                continue;
+            }
+            forms_apply(du, aut);
+            const T tau = fmax(tau_min, (T)1 - mu);
+            T ap = 1, lg = 0;
+            ad = 1;
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                if (fv[i]) {
+                    const T su = bu[i] - au[i], sl = bl[i] + au[i], dsu = -aut[i], dsl = aut[i];
+                    const T dlu = (mu - lu[i] * su) / su - lu[i] / su * dsu;
+                    const T dll = (mu - ll[i] * sl) / sl - ll[i] / sl * dsl;
+                    if (dsu < 0) ap = fmin(ap, -tau * su / dsu);
+                    if (dsl < 0) ap = fmin(ap, -tau * sl / dsl);
+                    if (dlu < 0) ad = fmin(ad, -tau * lu[i] / dlu);
+                    if (dll < 0) ad = fmin(ad, -tau * ll[i] / dll);
+                    lg += log(su * sl);
+                }
+            ap = dpp_min(ap); ad = dpp_min(ad);
+            phi0 = sc * J - mu * dpp_sum(lg);
+            dphi = dpp_sum(lane < n ? -rhs * du : (T)0);
+            alpha = ap; ls = 0;
+            Ut = U + alpha * du;
+            mode = TRIAL;
+            STAMP(8);
         }
         STAMP(10);
-        // ---- outputs ----------------------------------------------------------------------------
+        // ---- outputs (St / Jt are the evaluation of the returned U) ------------------------------------
         forms_apply(U, au);
-        J = eval(U, S);
         T viol = -(T)1e30;
 #pragma unroll
         for (int i = 0; i < NF; ++i)
@@ -722,13 +737,13 @@ template <typename T, int N> struct FastSolver {
         }
         if (io.outX && lane <= N) {
             T *o = io.outX + ((size_t)b * (N + 1) + lane) * 4;
-            o[0] = S.x; o[1] = S.y; o[2] = S.psi; o[3] = S.v;
+            o[0] = St.x; o[1] = St.y; o[2] = St.psi; o[3] = St.v;
         }
         STAMP(11);
         STAMP_OUT(io.stamps, b);
         if (lane == 0) {
             io.status[b] = status;
-            if (io.cost) io.cost[b] = J;
+            if (io.cost) io.cost[b] = Jt;
             if (io.viol) io.viol[b] = viol;
             if (io.iters) io.iters[b] = iters;
         }
@@ -736,7 +751,7 @@ template <typename T, int N> struct FastSolver {
 };
 
 template <typename T, int N>
-__global__ __launch_bounds__(64, 3) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(64, 4) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N>::lds_elems() * sizeof(T)];
     const int b = blockIdx.x;
