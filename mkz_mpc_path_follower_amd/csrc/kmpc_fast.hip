@@ -82,8 +82,8 @@ template <typename T> DEV void sincos_mid(T x, T *s, T *c) {
 template <typename T> struct StageF {  // lane k: state k / input k at the evaluated point
     T a, d, v, x, y, psi, c, s, sinb, cosb, b1, b2, ex, ey, ep, ev;
 };
-// linearisation scalars of stage k, parked in LDS (16 words per stage, aliasing the K image, which is
-// idle between a factorisation and the next build_K): A02 A03 A12 A13 A23 Bdx Bdy Bdp mpp mpv mpd mvd mdd
+// linearisation scalars of stage k, parked in LDS (16 words per stage):
+// A02 A03 A12 A13 A23 Bdx Bdy Bdp mpp mpv mpd mvd mdd 0
 constexpr int LIN_STRIDE = 16;
 
 template <typename T, int N> struct FastSolver {
@@ -95,8 +95,7 @@ template <typename T, int N> struct FastSolver {
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
     static_assert(n + 1 <= 64 && n % 8 == 0, "fast kernel needs 2N + 1 <= 64 and N % 4 == 0");
     typedef typename Real<T>::acc_t acc_t;
-    static_assert(LIN_STRIDE * (N + 1) <= LC, "stage scalars must fit in the K image");
-    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64; }
+    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1); }
     // start of column j minus j, so that element (row i, col j) lives at offc(j) + i
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
@@ -104,7 +103,7 @@ template <typename T, int N> struct FastSolver {
     const KP &P;
     int lane;  // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the
                // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
-    T *Lc, *xb, *wb, *cb;
+    T *Lc, *xb, *wb, *cb, *lin;
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp;
     T dt, dtc, Lb, rr_, Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
 
@@ -114,6 +113,7 @@ template <typename T, int N> struct FastSolver {
         xb = Lc + ((LC + 1) & ~1);
         wb = xb + 64;
         cb = wb + 64 * NF;
+        lin = cb + 64;
         dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
         Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
         Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
@@ -302,7 +302,7 @@ template <typename T, int N> struct FastSolver {
                   pp1 * (dt * v / Lb * (-S.sinb * b1 * b1 + S.cosb * b2));
         }
         {
-            T *q = Lc + LIN_STRIDE * (k <= N ? k : N);
+            T *q = lin + LIN_STRIDE * (k <= N ? k : N);
             T *dmy = xb + 48;  // lanes > N write nowhere that matters
             T *w0 = k <= N ? q : dmy;
             w0[0] = A02; w0[1] = A03;
@@ -315,8 +315,12 @@ template <typename T, int N> struct FastSolver {
         return g;
     }
 
-    // condensing on the matrix cores; ROLLED stage loop (runtime s), static register indices
-    DEV void condense(bool exact, acc_t (&acc)[NTT])
+    // Condensing on the matrix cores; ROLLED stage loop (runtime s), static register indices.
+    // acc (lower 16x16 tiles, MFMA C layout) accumulates sum_s G_s^T (2 Q_s + M_s^{psi,v}) G_s (unscaled).
+    // The remaining second-order rows -- row rho = 2s+1 (d_f of stage s): mpd*G_psi + mvd*G_v, mdd on the
+    // diagonal -- are written, scaled by sc, straight into the packed K image by the lanes that hold those
+    // columns; they define every ODD row of the image (build_K then adds to odd rows, stores even rows).
+    DEV void condense(bool exact, T sc, acc_t (&acc)[NTT])
     {
         const int kk = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -333,14 +337,19 @@ template <typename T, int N> struct FastSolver {
         const int iE = kk >= 2 ? 9 : 13;                                  // 0   | 0   | mpv | mpv
         const T o0 = kk == 3 ? dt : (T)0;
         const T dbase = kk == 0 ? (T)2 * Cx : (kk == 1 ? (T)2 * Cy : (kk == 2 ? (T)2 * Cp : (T)0));
+        const T exs = exact ? (T)1 : (T)0;
+        // software pipeline: coefficients of the transition s-1 -> s are fetched one stage ahead
+        T cA = 0, cB = 0, bo = 0, A23 = 0, Bdp = 0;
+        T mppl = lin[iD], mpvl = lin[iE], mpd = lin[10], mvd = lin[11], mdd = lin[12];  // stage 0
 #pragma nounroll
         for (int s = 0; s <= N; ++s) {
-            const T *qs = Lc + LIN_STRIDE * (s < N ? s : N - 1);  // second-order scalars of stage s (unused at s = N)
-            const T ex_ = (exact && s < N) ? (T)1 : (T)0;
-            const T mppl = qs[iD], mpvl = qs[iE], mpd = ex_ * qs[10], mvd = ex_ * qs[11], mdd = ex_ * qs[12];
+            // prefetch for the next stage (clamped at the end; values unused there)
+            const T *qn = lin + LIN_STRIDE * (s < N ? s : N - 1);         // transition s -> s+1
+            const T *qs = lin + LIN_STRIDE * (s + 1 < N ? s + 1 : N - 1);  // second-order scalars of stage s+1
+            const T ncA = qn[iA], ncB = qn[iB], nbo = qn[iO], nA23 = qn[4], nBdp = qn[7];
+            const T nmppl = qs[iD], nmpvl = qs[iE], nmpd = qs[10], nmvd = qs[11], nmdd = qs[12];
+            const T ex_ = (s < N) ? exs : (T)0;
             if (s >= 1) {
-                const T *q = Lc + LIN_STRIDE * (s - 1);
-                const T cA = q[iA], cB = q[iB], bo = q[iO], A23 = q[4], Bdp = q[7];
                 const int col0 = 2 * (s - 1), t0 = col0 >> 4;
                 const bool m0 = c == (col0 & 15), m1 = c == (col0 & 15) + 1;
 #pragma unroll
@@ -366,23 +375,19 @@ template <typename T, int N> struct FastSolver {
                             acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[ti * (ti + 1) / 2 + tj]);
                     }
             }
-            if (exact && s < N) {
-                // row rho = 2s+1 (d_f of stage s) of the second-order term as a rank-1 MFMA:
-                // A = e_rho (k-slot 0), B = mpd*G_psi + mvd*G_v (+ mdd on the diagonal)
-                const int rho = 2 * s + 1, rt = rho >> 4, rr = rho & 15;
-                const T aop = (kk == 0 && c == rr) ? (T)1 : (T)0;
+            if (s < N) {  // odd row rho = 2s+1 of the image (zero second-order part when !exact)
+                const int rho = 2 * s + 1;
+                const T a = sc * ex_ * mpd, bq = sc * ex_ * mvd, dq = sc * ex_ * mdd;
 #pragma unroll
-                for (int ti = 0; ti < NT; ++ti)
-                    if (ti == rt) {
-#pragma unroll
-                        for (int tj = 0; tj <= ti; ++tj) {
-                            T b = mpd * gps[tj] + mvd * gv[tj];
-                            if (tj == ti) b += (c == rr) ? mdd : (T)0;
-                            b = kk == 0 ? b : (T)0;
-                            acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(aop, b, acc[ti * (ti + 1) / 2 + tj]);
-                        }
-                    }
+                for (int t = 0; t < NT; ++t) {
+                    const int col = 16 * t + c;
+                    const bool okw = kk == 0 && col <= rho;
+                    T *dst = okw ? Lc + offc_rt(okw ? col : 0) + rho : xb + lane;
+                    *dst = a * gps[t] + bq * gv[t] + (col == rho ? dq : (T)0);
+                }
             }
+            cA = ncA; cB = ncB; bo = nbo; A23 = nA23; Bdp = nBdp;
+            mppl = nmppl; mpvl = nmpvl; mpd = nmpd; mvd = nmvd; mdd = nmdd;
         }
     }
 
@@ -410,7 +415,8 @@ template <typename T, int N> struct FastSolver {
                     const int col = 16 * tj + c;
                     const bool ok = row < n && col <= row;
                     T *dst = ok ? Lc + offc_rt(ok ? col : 0) + row : xb + lane;
-                    *dst = sc * acc[ti * (ti + 1) / 2 + tj][r] + sp;
+                    const T v = sc * acc[ti * (ti + 1) / 2 + tj][r] + sp;
+                    *dst = (row & 1) ? *dst + v : v;  // odd rows already hold the second-order rows (condense)
                 }
             }
         (void)ee; (void)q;
@@ -443,14 +449,18 @@ template <typename T, int N> struct FastSolver {
             ok = ok && (d > Real<T>::tiny()) && (d < (T)1e300);
             const T rinv = rsqrt_(d);
             const T l = slot[0] * rinv;  // L[lane][j] (lanes < j hold garbage that nothing reads)
-            T *dst = (lane >= j && lane <= n) ? Lc + offc_rt(j) + lane : xb + lane;  // branch-free: others hit a dummy word
-            *dst = l;                     // kept for the Schur phase and the backward substitution
-            // rank-1 update; the multiplier L[j+1+p][j] is lane (j+1+p)'s own l: v_readlane, no LDS round trip
+            const int oc = offc_rt(j);
+            T *dst = (lane >= j && lane <= n) ? Lc + oc + lane : xb + lane;  // branch-free: others hit a dummy word
+            *dst = l;                     // column j of L: broadcast source now, Schur / back-substitution input later
+            WFENCE();
+            // rank-1 update: fetch ALL multipliers L[j+1+p][j] first (uniform-address LDS reads, issued back to
+            // back into registers), then the FMAs back to back -- no per-entry dependency stall
+            const T *pb = Lc + oc + j + 1;
+            T m[LEN];
 #pragma unroll
-            for (int p = 0; p < LEN; ++p) {
-                const int src = j + 1 + p;
-                slot[p] = fma(-l, readlane_(l, src < 64 ? src : 63), slot[p + 1 < N ? p + 1 : N - 1]);
-            }
+            for (int p = 0; p < LEN; ++p) m[p] = pb[p];
+#pragma unroll
+            for (int p = 0; p < LEN; ++p) slot[p] = fma(-l, m[p], slot[p + 1 < N ? p + 1 : N - 1]);
         }
     }
 
@@ -473,16 +483,45 @@ template <typename T, int N> struct FastSolver {
         chol_sweep<L1>(slot, 0, h / 2, ok);
         chol_sweep<L2>(slot, h / 2, h, ok);
         WFENCE();
+        // ---- phase 2: trailing block (rows h..n incl. the rhs row, columns h..n-1) -= L21 L21^T on the
+        // matrix cores.  L21[i][j] (i >= h, j < h) sits in the packed LDS columns; for the 16x16x4 MFMA both
+        // operands of tile (tr, tc) are "row block of L21, 4 columns": lane (i = l&15, k = l>>4) reads
+        // L21[h + 16*t + i][4*kc + k], so the A fragment of tile-row t is also the B fragment of tile-col t.
+        {
+            constexpr int TR = (n + 1 - h + 15) / 16;  // 16-row blocks of the trailing rows (2 at N = 20)
+            constexpr int KC = h / 4;
+            acc_t sacc[TR * (TR + 1) / 2];
+#pragma unroll
+            for (int t = 0; t < TR * (TR + 1) / 2; ++t) sacc[t] = acc_t{0, 0, 0, 0};
+            const int fi = lane & 15, fk = lane >> 4;
+#pragma nounroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const T *pcol = Lc + offc_rt(4 * kc + fk) + h + fi;
+                T frag[TR];
+#pragma unroll
+                for (int t = 0; t < TR; ++t) frag[t] = pcol[16 * t];
+#pragma unroll
+                for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+                    for (int tc = 0; tc <= tr; ++tc)
+                        sacc[tr * (tr + 1) / 2 + tc] = Real<T>::mfma(frag[tr], frag[tc], sacc[tr * (tr + 1) / 2 + tc]);
+            }
+            const int c = lane & 15;
+#pragma unroll
+            for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+                for (int tc = 0; tc <= tr; ++tc)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = h + 16 * tr + Real<T>::row_of(lane, r), col = h + 16 * tc + c;
+                        const bool okw = row <= n && col < n && col <= row;
+                        T *dst = okw ? Lc + offc_rt(okw ? col : 0) + row : xb + lane;
+                        *dst -= sacc[tr * (tr + 1) / 2 + tc][r];
+                    }
+        }
+        WFENCE();
 #pragma unroll
         for (int e = 0; e < h; ++e) slot[e] = Lc[offc(h + e) + lane];
-        T li = Lc[offc_rt(0) + lane];
-#pragma nounroll
-        for (int j = 0; j < h; ++j) {  // trailing block -= L21 L21^T, one column of L21 per pass
-            const T lc = li;
-            li = Lc[offc_rt(j + 1 < h ? j + 1 : j) + lane];  // prefetch the next column's entry of this row
-#pragma unroll
-            for (int e = 0; e < h; ++e) slot[e] = fma(-lc, readlane_(lc, h + e), slot[e]);  // L[h+e][j] is lane h+e's lc
-        }
         chol_sweep<L1>(slot, h, h + h / 2, ok);
         chol_sweep<L2>(slot, h + h / 2, n, ok);
         if (!ok) return false;
@@ -681,7 +720,7 @@ template <typename T, int N> struct FastSolver {
             bool factored;
             {
                 acc_t acc[NTT];
-                condense(use_exact, acc);
+                condense(use_exact, sc, acc);
                 STAMP(3);
                 build_K(acc, sc, reg, rhs);
                 STAMP(4);
@@ -750,8 +789,11 @@ template <typename T, int N> struct FastSolver {
     }
 };
 
+// waves per SIMD: the fp64 kernel needs ~250 VGPRs to run without scratch spills (measured: at 128 VGPRs the
+// spills moved 1.6 GB of HBM traffic per 4096-problem launch against 2.4 MB of algorithmic bytes); the kernel is
+// issue-bound, not occupancy-bound, so 2 waves/SIMD without spills beats 4 with.  fp32 fits 3 waves spill-free.
 template <typename T, int N>
-__global__ __launch_bounds__(64, 4) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : 3) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N>::lds_elems() * sizeof(T)];
     const int b = blockIdx.x;
