@@ -592,7 +592,8 @@ template <typename T, int N> struct FastSolver {
         bool fv[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i]); lu[i] = ll[i] = au[i] = aut[i] = (T)0; }
-        int status = 1, iters = 0, ls = 0, attempt = 0;
+        int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0;
+        T err_last = (T)1e30;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, Jt = 0, alpha = 0, ad = 0, phi0 = 0, dphi = 0, reg = 0;
         bool use_exact = exact;
         enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3 };
@@ -643,7 +644,7 @@ template <typename T, int N> struct FastSolver {
                 okp = __all(okp);
                 const T phi = sc * Jt - mu * dpp_sum(lgt);
                 if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi)) {
-                    if (++ls >= P.max_ls) { status = 3; mode = FINAL; Ut = U; continue; }
+                    if (++ls >= P.max_ls) { status = err_last <= (T)100 * tol ? 0 : 3; mode = FINAL; Ut = U; continue; }  // acceptable level
                     alpha *= (T)0.5;
                     Ut = U + alpha * du;
                     continue;
@@ -694,8 +695,16 @@ template <typename T, int N> struct FastSolver {
                 const T s_d = fmax(s_max, lsum / (T)(2 * nf)) / s_max;
                 const T err0 = fmax(rdm, cm0) / s_d;
                 const T gap_lim = gap_tol * fmax((T)1, fabs(J));
-                if (err0 <= tol && gap / sc <= gap_lim) { status = 0; mode = FINAL; Ut = U; continue; }
-                const T mu_min = fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf));
+                err_last = err0;
+                // Ipopt's test (+ gap bound, pursued for at most 3 more iterations once Ipopt's test is met), or
+                // Ipopt's "acceptable level" (error <= 100*tol for 15 iterations in a row)
+                bool done = false;
+                if (err0 <= tol) {
+                    if (gap / sc <= gap_lim || n_polish >= 3) done = true; else ++n_polish;
+                } else if (n_polish > 0 && ++n_polish > 3) done = true;
+                n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
+                if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
+                const T mu_min = fmax(tol * (T)1e-3, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
 #pragma nounroll
                 for (;;) {  // monotone barrier update
                     T cmu = 0;

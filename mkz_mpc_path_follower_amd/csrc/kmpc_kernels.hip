@@ -456,7 +456,7 @@ template <typename T, int NT> struct Solver {
         bool fv[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i], rlx[i]); }
-        int status = 1, iters = 0;
+        int status = 1, iters = 0, n_polish = 0, n_accept = 0;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, err0 = 0;
         Stage<T> S, St;
         acc_t acc[NTT];
@@ -533,8 +533,15 @@ template <typename T, int NT> struct Solver {
                 err0 = fmax(rdm, cm0) / s_d;
                 // Ipopt's scaled test + an unscaled duality-gap bound: cost within gap_tol*max(1,|J|) of optimal
                 const T gap_lim = gap_tol * fmax((T)1, fabs(J));
-                if (err0 <= tol && gap / sc <= gap_lim) { status = 0; break; }
-                const T mu_min = fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf));
+                // Ipopt's test (+ gap bound, pursued for at most 3 more iterations once Ipopt's test is met), or
+                // Ipopt's "acceptable level" (error <= 100*tol for 15 iterations in a row)
+                if (err0 <= tol) {
+                    if (gap / sc <= gap_lim || n_polish >= 3) { status = 0; break; }
+                    ++n_polish;
+                } else if (n_polish > 0 && ++n_polish > 3) { status = 0; break; }
+                n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
+                if (n_accept >= 15) { status = 0; break; }
+                const T mu_min = fmax(tol * (T)1e-3, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
                 for (;;) {  // monotone barrier update
                     T cmu = 0;
 #pragma unroll
@@ -621,7 +628,7 @@ template <typename T, int NT> struct Solver {
                     if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; break; }
                 }
                 STAMP(9);
-                if (!accepted) { status = 3; break; }
+                if (!accepted) { status = err0 <= (T)100 * tol ? 0 : 3; break; }  // acceptable level reached
 #pragma unroll
                 for (int i = 0; i < NV; ++i) U[i] = Ut[i];
                 S = St; J = Jt;
