@@ -39,6 +39,15 @@ def algorithmic_flops_per_iteration(N):
     return 150 * N + 32 * N * N + f_cond + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
 
 
+def measured_traffic_bytes():
+    """HBM bytes per 4096-problem dispatch from the committed PMC passes (profiles/r1_pmc_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            return float(json.load(f)["runs"]["v4_256vgpr_spill_free"]["hbm_bytes_per_dispatch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(N, d, budget_s=15.0):
     """oracle/ CPU port (same algorithm, scalar C, pthreads over problems) on a bounded sample."""
     from oracle import oracle as O
@@ -129,6 +138,7 @@ def main():
         byts = algorithmic_bytes_per_solve(N, es) * Bl
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
         ach_gbs = byts / (kern_ms * 1e-3) / 1e9
+        traffic = measured_traffic_bytes() if (world == 1 and Bl == 4096 and N == 20 and a.dtype == "f64") else None
         res = {
             "metric": "MPC solves/sec (batch, N=20 bicycle)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
@@ -139,11 +149,11 @@ def main():
                        "mean_iterations": iters, "optimal_fraction": n_opt / Bl},
             # the path is compute/latency-bound: fp64 VALU+MFMA roofline is the binding one
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "kmpc_solve_kernel", "kernel_ms": kern_ms,
+                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "kmpc_solve_fast_kernel<double,20>" if (N == 20 and a.dtype == "f64") else "kmpc_solve_kernel", "kernel_ms": kern_ms,
                          "flops_per_solve": algorithmic_flops_per_iteration(N) * iters},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                             "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": byts,
                              "bytes_per_solve": algorithmic_bytes_per_solve(N, es)},
         }
         if world == 1:
