@@ -129,6 +129,28 @@ int32_t kmpc_debug_condense(kmpc_handle *h, int32_t B, const void *z0, const voi
 /* raw v_mfma_{f64,f32}_16x16x4 probe: a[64], b[64] lane operands -> d[64*4] lane-major results */
 int32_t kmpc_debug_mfma_probe(kmpc_handle *h, const void *a, const void *b, void *d, void *stream);
 
+/* ---- batched look-ahead waypoints: the step before the solve ------------------------------------
+ * Replaces GPSRefTrajectory of scripts/gps_utils/ref_gps_traj.py: the constructor's path arrays
+ * (:87-106; projection and arclength are computed by the host, see ref_traj.py) and
+ * get_waypoints(X_init, Y_init, yaw_init[, v_target]) (:131-142, 172-218) for B vehicles at once. */
+typedef struct kmpc_path kmpc_path;
+
+/* HOST arrays of length M: time stamps, X, Y (m), psi (rad) and cumulative distance of the recorded path
+ * (columns 0, 4, 5, 3, 6 of GPSRefTrajectory.trajectory, :106); they are copied to `device`. */
+int32_t kmpc_path_create(int32_t device, int32_t M, const double *t, const double *X, const double *Y,
+                         const double *psi, const double *cdist, kmpc_path **out);
+int32_t kmpc_path_destroy(kmpc_path *p);
+
+/* DEVICE pointers, fp64: pose [B,3] = (X_init, Y_init, yaw_init); v_target [B] (target-velocity mode,
+ * waypoints start ONE step ahead, :175) or NULL (time mode, start at the closest point, :191);
+ * ref_out [B,horizon+1,3] = (x_ref, y_ref, psi_ref) per stage -- the layout kmpc_solve_batch takes;
+ * stop_out [B] int32 (stop_cmd, :182-184); closest_out [B] int32 or NULL (index of the nearest sample).
+ * Asynchronous on `stream`. */
+int32_t kmpc_waypoints_batch(kmpc_path *p, int32_t B, int32_t horizon, double traj_dt, const double *pose,
+                             const double *v_target, double *ref_out, int32_t *stop_out, int32_t *closest_out,
+                             void *stream);
+const char *kmpc_path_last_error(kmpc_path *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -270,3 +270,73 @@ extern "C" int32_t kmpc_debug_mfma_probe(kmpc_handle *h, const void *a, const vo
     else HIPCHK(h, kmpc_launch_probe<float>((const float *)a, (const float *)b, (float *)d, st));
     return KMPC_OK;
 }
+
+// ---- batched waypoint generation (scripts/gps_utils/ref_gps_traj.py) -------------------------------
+struct WP {
+    int M, B, H;
+    int use_vtarget;
+    double traj_dt;
+    const double *t, *X, *Y, *psi, *s;
+    const double *pose;
+    const double *vt;
+    double *ref;
+    int32_t *stop;
+    int32_t *closest;
+};
+hipError_t kmpc_launch_waypoints(const WP &w, hipStream_t st);
+
+struct kmpc_path {
+    int device, M;
+    double *d;  // t | X | Y | psi | s, each M doubles
+    std::string err;
+};
+
+extern "C" int32_t kmpc_path_create(int32_t device, int32_t M, const double *t, const double *X, const double *Y,
+                                    const double *psi, const double *cdist, kmpc_path **out)
+{
+    if (!out || M < 2 || !t || !X || !Y || !psi || !cdist) return fail(nullptr, KMPC_ERR_ARG, "kmpc_path_create: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_path_create: no HIP device");
+    if (device < 0 || device >= ndev) return fail(nullptr, KMPC_ERR_ARG, "kmpc_path_create: device %d of %d", device, ndev);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, KMPC_ERR_HIP, "kmpc_path_create: hipSetDevice failed");
+    kmpc_path *p = new kmpc_path();
+    p->device = device; p->M = M; p->d = nullptr;
+    if (hipMalloc((void **)&p->d, (size_t)5 * M * sizeof(double)) != hipSuccess) { delete p; return fail(nullptr, KMPC_ERR_HIP, "kmpc_path_create: hipMalloc failed"); }
+    const double *src[5] = {t, X, Y, psi, cdist};
+    for (int i = 0; i < 5; ++i)
+        if (hipMemcpy(p->d + (size_t)i * M, src[i], (size_t)M * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(p->d); delete p;
+            return fail(nullptr, KMPC_ERR_HIP, "kmpc_path_create: hipMemcpy failed");
+        }
+    *out = p;
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_path_destroy(kmpc_path *p)
+{
+    if (!p) return KMPC_OK;
+    (void)hipSetDevice(p->device);
+    (void)hipFree(p->d);
+    delete p;
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_waypoints_batch(kmpc_path *p, int32_t B, int32_t horizon, double traj_dt, const double *pose,
+                                        const double *v_target, double *ref_out, int32_t *stop_out, int32_t *closest_out,
+                                        void *stream)
+{
+    if (!p) return KMPC_ERR_ARG;
+    if (B < 0 || horizon < 1 || horizon > 63 || !(traj_dt > 0)) { p->err = "kmpc_waypoints_batch: bad B / horizon / traj_dt"; return KMPC_ERR_ARG; }
+    if (B == 0) return KMPC_OK;
+    if (!pose || !ref_out || !stop_out) { p->err = "kmpc_waypoints_batch: null required buffer"; return KMPC_ERR_ARG; }
+    if (hipSetDevice(p->device) != hipSuccess) { p->err = "hipSetDevice failed"; return KMPC_ERR_HIP; }
+    WP w;
+    w.M = p->M; w.B = B; w.H = horizon; w.use_vtarget = v_target ? 1 : 0; w.traj_dt = traj_dt;
+    w.t = p->d; w.X = p->d + p->M; w.Y = p->d + 2 * (size_t)p->M; w.psi = p->d + 3 * (size_t)p->M; w.s = p->d + 4 * (size_t)p->M;
+    w.pose = pose; w.vt = v_target; w.ref = ref_out; w.stop = stop_out; w.closest = closest_out;
+    hipError_t e = kmpc_launch_waypoints(w, (hipStream_t)stream);
+    if (e != hipSuccess) { p->err = std::string("waypoints launch failed: ") + hipGetErrorString(e); return KMPC_ERR_HIP; }
+    return KMPC_OK;
+}
+
+extern "C" const char *kmpc_path_last_error(kmpc_path *p) { return p ? p->err.c_str() : g_create_err.c_str(); }

@@ -593,7 +593,8 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i]); lu[i] = ll[i] = au[i] = aut[i] = (T)0; }
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0;
-        T err_last = (T)1e30;
+        T err_last = (T)1e30, Ubest = 0;
+        bool have_best = false;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, Jt = 0, alpha = 0, ad = 0, phi0 = 0, dphi = 0, reg = 0;
         bool use_exact = exact;
         enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3 };
@@ -629,6 +630,10 @@ template <typename T, int N> struct FastSolver {
 #pragma nounroll
         for (;;) {
             asm volatile("" : "+v"(lane));
+            if (mode == FINAL && have_best && !(status == 0 && err_last <= tol)) {
+                // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
+                Ut = Ubest; U = Ubest; status = 0;
+            }
             Jt = eval(Ut, St);
             STAMP(9);
             if (mode == FINAL) break;
@@ -696,15 +701,16 @@ template <typename T, int N> struct FastSolver {
                 const T err0 = fmax(rdm, cm0) / s_d;
                 const T gap_lim = gap_tol * fmax((T)1, fabs(J));
                 err_last = err0;
-                // Ipopt's test (+ gap bound, pursued for at most 3 more iterations once Ipopt's test is met), or
+                // Ipopt's test (+ gap bound, pursued for at most 1 more iteration once Ipopt's test is met), or
                 // Ipopt's "acceptable level" (error <= 100*tol for 15 iterations in a row)
                 bool done = false;
+                if (err0 <= tol) { Ubest = U; have_best = true; }  // last iterate passing Ipopt's test
                 if (err0 <= tol) {
-                    if (gap / sc <= gap_lim || n_polish >= 3) done = true; else ++n_polish;
-                } else if (n_polish > 0 && ++n_polish > 3) done = true;
+                    if (gap / sc <= gap_lim || n_polish >= 1) done = true; else ++n_polish;
+                } else if (n_polish > 0 && ++n_polish > 1) done = true;
                 n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
                 if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
-                const T mu_min = fmax(tol * (T)1e-3, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
+                const T mu_min = fmax(tol * (T)1e-2, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
 #pragma nounroll
                 for (;;) {  // monotone barrier update
                     T cmu = 0;

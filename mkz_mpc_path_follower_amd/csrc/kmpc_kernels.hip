@@ -457,6 +457,10 @@ template <typename T, int NT> struct Solver {
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i], rlx[i]); }
         int status = 1, iters = 0, n_polish = 0, n_accept = 0;
+        bool have_best = false;
+        T Ubest[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) Ubest[i] = (T)0;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, err0 = 0;
         Stage<T> S, St;
         acc_t acc[NTT];
@@ -533,15 +537,20 @@ template <typename T, int NT> struct Solver {
                 err0 = fmax(rdm, cm0) / s_d;
                 // Ipopt's scaled test + an unscaled duality-gap bound: cost within gap_tol*max(1,|J|) of optimal
                 const T gap_lim = gap_tol * fmax((T)1, fabs(J));
-                // Ipopt's test (+ gap bound, pursued for at most 3 more iterations once Ipopt's test is met), or
+                // Ipopt's test (+ gap bound, pursued for at most 1 more iteration once Ipopt's test is met), or
                 // Ipopt's "acceptable level" (error <= 100*tol for 15 iterations in a row)
+                if (err0 <= tol) {  // remember the last iterate passing Ipopt's test
+                    have_best = true;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Ubest[i] = U[i];
+                }
                 if (err0 <= tol) {
-                    if (gap / sc <= gap_lim || n_polish >= 3) { status = 0; break; }
+                    if (gap / sc <= gap_lim || n_polish >= 1) { status = 0; break; }
                     ++n_polish;
-                } else if (n_polish > 0 && ++n_polish > 3) { status = 0; break; }
+                } else if (n_polish > 0 && ++n_polish > 1) { status = 0; break; }
                 n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
                 if (n_accept >= 15) { status = 0; break; }
-                const T mu_min = fmax(tol * (T)1e-3, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
+                const T mu_min = fmax(tol * (T)1e-2, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
                 for (;;) {  // monotone barrier update
                     T cmu = 0;
 #pragma unroll
@@ -643,6 +652,13 @@ template <typename T, int NT> struct Solver {
             }
         }
         STAMP(10);
+        // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
+        if (have_best && !(status == 0 && err0 <= tol)) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) U[i] = Ubest[i];
+            status = 0;
+            J = eval(U, S);
+        }
         // ---- outputs ----------------------------------------------------------------------------
         forms_apply(U, au);
         T viol = -(T)1e30;

@@ -344,7 +344,9 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc
     const double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, kappa_sigma = 1e10,
                  eta_phi = 1e-8, s_max = 100.0;
     const double gap_tol = 1e-7;
-    const int max_polish = 3;
+    const int max_polish = 1;
+    int have_best = 0;
+    double *Ubest = (double *)malloc((size_t)(n + 2 * nf) * sizeof(double));
     int n_polish = 0, n_accept = 0;
 
     forms_bounds(p, q, o->bound_relax, &F, bu, bl);
@@ -410,13 +412,19 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc
         /* termination: Ipopt's test (+ the gap bound, pursued for at most max_polish further iterations once
            Ipopt's test has been met: below mu ~ 1e-11 round-off defeats the line search), or Ipopt's
            "acceptable level": error <= acceptable_tol (100*tol) for acceptable_iter (15) iterations in a row */
+        if (err0 <= o->tol) { /* last iterate passing Ipopt's test (with its multipliers, for the certifier) */
+            memcpy(Ubest, U, (size_t)n * sizeof(double));
+            memcpy(Ubest + n, lu, (size_t)nf * sizeof(double));
+            memcpy(Ubest + n + nf, ll, (size_t)nf * sizeof(double));
+            have_best = 1;
+        }
         if (err0 <= o->tol) {
             if (gap / sc <= gap_lim || n_polish >= max_polish) { status = KMPC_OPTIMAL; break; }
             ++n_polish;
         } else if (n_polish > 0 && ++n_polish > max_polish) { status = KMPC_OPTIMAL; break; }
         n_accept = err0 <= 100.0 * o->tol ? n_accept + 1 : 0;
         if (n_accept >= 15) { status = KMPC_OPTIMAL; break; }
-        const double mu_min = fmax(o->tol * 1e-3, fmin(o->tol / 10.0, 0.1 * gap_lim * sc / (2.0 * nf)));
+        const double mu_min = fmax(o->tol * 1e-2, fmin(o->tol / 10.0, 0.1 * gap_lim * sc / (2.0 * nf)));
         /* monotone barrier update (Ipopt eq. (7)) */
         for (;;) {
             double cmu = 0.0;
@@ -494,6 +502,14 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc
     }
 
 finish:
+    /* any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed */
+    if (have_best && !(status == KMPC_OPTIMAL && err0 <= o->tol)) {
+        memcpy(U, Ubest, (size_t)n * sizeof(double));
+        memcpy(lu, Ubest + n, (size_t)nf * sizeof(double));
+        memcpy(ll, Ubest + n + nf, (size_t)nf * sizeof(double));
+        status = KMPC_OPTIMAL;
+    }
+    free(Ubest);
     kmpc_rollout(p, q->z0, U, Xl);
     if (X) memcpy(X, Xl, (size_t)(N + 1) * 4 * sizeof(double));
     if (lam_out) {
