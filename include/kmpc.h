@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KMPC_ABI_VERSION 1
+#define KMPC_ABI_VERSION 2
 
 /* per-problem status, replaces the Symbol returned by solve_model() (MKZMPCPathFollower.jl:176,182) */
 enum {
@@ -70,6 +70,11 @@ typedef struct kmpc_config {
     double warm_mu;      /* mu_init used with a warm start */
     int32_t max_ls;      /* back-tracking trial points per iteration */
     int32_t kernel_variant; /* 0 = auto (compile-time-horizon kernel when one is built for N, else generic), 1 = generic */
+    int32_t mu_strategy;    /* barrier update: 0 = Ipopt's default monotone (Fiacco-McCormick), 1 = Mehrotra predictor-corrector
+                               (Ipopt's adaptive family); kmpc_config_default picks 1 for N <= 24, 0 for longer horizons */
+    int32_t indef_strategy; /* exact Hessian not positive definite: 0 = Gauss-Newton fallback (held for 2 iterations), 1 = Ipopt-style
+                               delta_w shift of the exact Hessian; kmpc_config_default picks 0 for N <= 24, 1 for longer horizons.
+                               (The compile-time-horizon kernel implements 0; 1 runs on the generic kernel.) */
 } kmpc_config;
 
 typedef struct kmpc_handle kmpc_handle;

@@ -79,6 +79,8 @@ extern "C" int32_t kmpc_config_default(kmpc_config *c, int32_t N, int32_t dtype)
     c->warm_push = 0.01;
     c->warm_mu = 1e-3;
     c->max_ls = 30;
+    c->indef_strategy = N <= 24 ? 0 : 1;  // indefinite exact Hessian: GN fallback for short horizons, delta_w shift for long ones
+    c->mu_strategy = N <= 24 ? 1 : 0;  // Mehrotra is validated for short horizons; longer ones keep Ipopt's monotone default
     return KMPC_OK;
 }
 
@@ -90,7 +92,8 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
     if (!(cfg->dt > 0) || !(cfg->dt_control > 0) || !(cfg->L_b > 0) || !(cfg->L_a + cfg->L_b > 0) ||
         !(cfg->v_max > cfg->v_min) || !(cfg->a_max > 0) || !(cfg->steer_max > 0) || !(cfg->steer_max < 1.5) ||
         !(cfg->a_dmax > 0) || !(cfg->steer_dmax > 0) || cfg->max_iter < 1 || cfg->max_ls < 1 || !(cfg->tol > 0) ||
-        cfg->kernel_variant < 0 || cfg->kernel_variant > 1)
+        cfg->kernel_variant < 0 || cfg->kernel_variant > 1 || cfg->mu_strategy < 0 || cfg->mu_strategy > 1 ||
+        cfg->indef_strategy < 0 || cfg->indef_strategy > 1)
         return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: invalid model / solver parameter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_create: no HIP device");
@@ -150,7 +153,7 @@ static KP make_kp(const kmpc_handle *h, int B, int warm, int hessian_override)
     memset(&P, 0, sizeof P);
     P.N = c.N; P.B = B; P.max_iter = c.max_iter;
     P.hessian = hessian_override >= 0 ? hessian_override : c.hessian;
-    P.warm = warm; P.max_ls = c.max_ls;
+    P.warm = warm; P.max_ls = c.max_ls; P.mu_strategy = c.mu_strategy; P.indef_strategy = c.indef_strategy;
     P.dt = c.dt; P.dtc = c.dt_control; P.L_b = c.L_b; P.r = c.L_b / (c.L_a + c.L_b);
     P.steer_max = c.steer_max; P.steer_dmax = c.steer_dmax; P.a_max = c.a_max; P.a_dmax = c.a_dmax;
     P.v_min = c.v_min; P.v_max = c.v_max;
@@ -171,7 +174,7 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
     io.iters = iters; io.outU = (T *)outU; io.outX = (T *)outX;
     io.stamps = g_stamps;
     const KP P = make_kp(h, B, warm && warmU ? 1 : 0, -1);
-    if (h->cfg.kernel_variant == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));
+    if (h->cfg.kernel_variant == 0 && P.indef_strategy == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));
     else HIPCHK(h, kmpc_launch_solve<T>(P, io, st));
     return KMPC_OK;
 }

@@ -52,10 +52,12 @@ template <typename T> DEV T scan_suffix(T x, int lane) {  // inclusive, lane 63 
 
 // phase stamps: diagnostic builds only (-DKMPC_STAMPS); the shipped library has none
 #ifdef KMPC_STAMPS
-#define STAMP_DECL unsigned long long st_t0_ = __builtin_readcyclecounter(), st_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define STAMP_MEMBERS unsigned long long st_t0_, st_acc_[16];
+#define STAMP_DECL do { st_t0_ = __builtin_readcyclecounter(); for (int i_ = 0; i_ < 16; ++i_) st_acc_[i_] = 0; } while (0);
 #define STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc_[i] += t_ - st_t0_; st_t0_ = t_; } while (0)
-#define STAMP_OUT(ptr, b) do { if ((ptr) && threadIdx.x == 0) for (int i_ = 0; i_ < 12; ++i_) (ptr)[(size_t)(b) * 12 + i_] = st_acc_[i_]; } while (0)
+#define STAMP_OUT(ptr, b) do { if ((ptr) && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) (ptr)[(size_t)(b) * 16 + i_] = st_acc_[i_]; } while (0)
 #else
+#define STAMP_MEMBERS
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_OUT(ptr, b)

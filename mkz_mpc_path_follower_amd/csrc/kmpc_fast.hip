@@ -26,11 +26,11 @@ DEV void pin(double &x) { asm volatile("" : "+v"(x)); }
 DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 
 DEV double rsqrt_(double d) {
-    double y = __builtin_amdgcn_rsq(d);
+    double y = __builtin_amdgcn_rsq(d);          // ~2^-26 relative
     double e = fma(-d * y, y, 1.0);
-    y = fma(y * e, fma(e, 0.375, 0.5), y);
+    y = fma(y * e, fma(e, 0.375, 0.5), y);      // cubic step: ~2^-78
     e = fma(-d * y, y, 1.0);
-    return fma(y * e, 0.5, y);
+    return fma(y * e, 0.5, y);                  // polish (guards the approximation's worst case)
 }
 DEV float rsqrt_(float d) {
     float y = __builtin_amdgcn_rsqf(d);
@@ -95,15 +95,17 @@ template <typename T, int N> struct FastSolver {
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
     static_assert(n + 1 <= 64 && n % 8 == 0, "fast kernel needs 2N + 1 <= 64 and N % 4 == 0");
     typedef typename Real<T>::acc_t acc_t;
-    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1); }
+    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64; }
     // start of column j minus j, so that element (row i, col j) lives at offc(j) + i
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
 
+    STAMP_MEMBERS
     const KP &P;
     int lane;  // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the
                // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
-    T *Lc, *xb, *wb, *cb, *lin;
+    T *Lc, *xb, *wb, *cb, *lin, *opb;
+    T dinv_l;  // 1 / L[lane][lane] of the current factor
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp;
     T dt, dtc, Lb, rr_, Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
 
@@ -114,6 +116,7 @@ template <typename T, int N> struct FastSolver {
         wb = xb + 64;
         cb = wb + 64 * NF;
         lin = cb + 64;
+        opb = lin + LIN_STRIDE * (N + 1);
         dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
         Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
         Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
@@ -315,79 +318,73 @@ template <typename T, int N> struct FastSolver {
         return g;
     }
 
-    // Condensing on the matrix cores; ROLLED stage loop (runtime s), static register indices.
-    // acc (lower 16x16 tiles, MFMA C layout) accumulates sum_s G_s^T (2 Q_s + M_s^{psi,v}) G_s (unscaled).
-    // The remaining second-order rows -- row rho = 2s+1 (d_f of stage s): mpd*G_psi + mvd*G_v, mdd on the
-    // diagonal -- are written, scaled by sc, straight into the packed K image by the lanes that hold those
-    // columns; they define every ODD row of the image (build_K then adds to odd rows, stores even rows).
+    // Condensing on the matrix cores.  H = sum_s G_s^T (2 Q_s + M_s^{psi,v}) G_s accumulates in `acc` (lower 16x16 tiles,
+    // MFMA C layout, unscaled).  The sensitivity recursion G_s = [A_{s-1} G_{s-1} | B_{s-1}] runs ONCE PER COLUMN
+    // (lane j = column j keeps its 4 components: 5 FMAs per stage); each stage's MFMA fragments -- A = G_s,
+    // B = (2Q_s + M_s) G_s -- go through a small component-major LDS buffer (opb[8][64]: conflict-free writes by column,
+    // conflict-free reads in fragment layout).  The loop is software-pipelined: while the fragments of stage s are in
+    // flight / on the matrix cores, the VALU advances the recursion to stage s+1.
+    // The remaining second-order rows -- row rho = 2s+1 (d_f of stage s): mpd*G_psi + mvd*G_v, mdd on the diagonal -- are
+    // written, scaled by sc, straight into the packed K image by the lane of each column; they define every ODD row of
+    // the image (build_K then adds to odd rows, stores even rows).
     DEV void condense(bool exact, T sc, acc_t (&acc)[NTT])
     {
         const int kk = lane >> 4, c = lane & 15;
 #pragma unroll
         for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
-        T own[NT], gps[NT], gv[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) own[t] = gps[t] = gv[t] = (T)0;
-        // per-lane word offsets into a stage record (word 13 is a stored zero): each lane fetches the
-        // coefficient ITS row needs, so no selects and one batch of independent ds_reads per stage
-        const int iA = kk == 0 ? 0 : (kk == 1 ? 2 : 13);                  // A02 | A12 | 0   | 0
-        const int iB = kk == 0 ? 1 : (kk == 1 ? 3 : (kk == 2 ? 4 : 13));  // A03 | A13 | A23 | 0
-        const int iO = kk == 0 ? 5 : (kk == 1 ? 6 : (kk == 2 ? 7 : 13));  // Bdx | Bdy | Bdp | 0
-        const int iD = kk == 2 ? 8 : 13;                                  // 0   | 0   | mpp | 0
-        const int iE = kk >= 2 ? 9 : 13;                                  // 0   | 0   | mpv | mpv
-        const T o0 = kk == 3 ? dt : (T)0;
-        const T dbase = kk == 0 ? (T)2 * Cx : (kk == 1 ? (T)2 * Cy : (kk == 2 ? (T)2 * Cp : (T)0));
+        T gx = 0, gy = 0, gp = 0, gv = 0;            // column `lane` of G at the current stage
+        const T pef = (lane & 1) ? (T)1 : (T)0;      // d_f columns take B's steering column, acc columns (0,0,0,dt)
+        const T gvnew = (lane & 1) ? (T)0 : dt;
+        T *colK = Lc + offc_rt(lane < n ? lane : 0);  // column `lane` of the packed K image
         const T exs = exact ? (T)1 : (T)0;
-        // software pipeline: coefficients of the transition s-1 -> s are fetched one stage ahead
-        T cA = 0, cB = 0, bo = 0, A23 = 0, Bdp = 0;
-        T mppl = lin[iD], mpvl = lin[iE], mpd = lin[10], mvd = lin[11], mdd = lin[12];  // stage 0
+        T fa[NT], fb[NT];                            // MFMA fragments of the stage in flight
 #pragma nounroll
         for (int s = 0; s <= N; ++s) {
-            // prefetch for the next stage (clamped at the end; values unused there)
-            const T *qn = lin + LIN_STRIDE * (s < N ? s : N - 1);         // transition s -> s+1
-            const T *qs = lin + LIN_STRIDE * (s + 1 < N ? s + 1 : N - 1);  // second-order scalars of stage s+1
-            const T ncA = qn[iA], ncB = qn[iB], nbo = qn[iO], nA23 = qn[4], nBdp = qn[7];
-            const T nmppl = qs[iD], nmpvl = qs[iE], nmpd = qs[10], nmvd = qs[11], nmdd = qs[12];
-            const T ex_ = (s < N) ? exs : (T)0;
+            // ---- stage s record: second-order scalars of stage s; transition s -> s+1 ------------------------------
+            const T *q = lin + LIN_STRIDE * (s < N ? s : N - 1);
+            const T ex_ = s < N ? exs : (T)0;
+            const T mpp = ex_ * q[8], mpv = ex_ * q[9], mpd = ex_ * q[10], mvd = ex_ * q[11], mdd = ex_ * q[12];
             if (s >= 1) {
-                const int col0 = 2 * (s - 1), t0 = col0 >> 4;
-                const bool m0 = c == (col0 & 15), m1 = c == (col0 & 15) + 1;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {  // G_s = [A_{s-1} G_{s-1} | B_{s-1}]  (columns not yet present are zero)
-                    own[t] += cA * gps[t] + cB * gv[t];
-                    gps[t] += A23 * gv[t];
-                    if (t == t0) {
-                        own[t] = m0 ? o0 : (m1 ? bo : own[t]);
-                        gps[t] = m0 ? (T)0 : (m1 ? Bdp : gps[t]);
-                        gv[t] = m0 ? dt : (m1 ? (T)0 : gv[t]);
-                    }
-                }
-                const T dco = dbase + ex_ * mppl + ((kk == 3 && s <= N - 1) ? (T)2 * Cv : (T)0);
-                const T oco = ex_ * mpvl;
-                T bop[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bop[t] = dco * own[t] + oco * (kk == 2 ? gv[t] : gps[t]);
+                // fragments of state s were issued at the end of the previous trip; feed the matrix cores
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
                     if (16 * ti < 2 * s) {
 #pragma unroll
                         for (int tj = 0; tj <= ti; ++tj)
-                            acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[ti * (ti + 1) / 2 + tj]);
+                            acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc[ti * (ti + 1) / 2 + tj]);
                     }
             }
-            if (s < N) {  // odd row rho = 2s+1 of the image (zero second-order part when !exact)
+            if (s < N) {
+                // odd row rho = 2s+1 of the image from G_s (zero second-order part when !exact)
                 const int rho = 2 * s + 1;
-                const T a = sc * ex_ * mpd, bq = sc * ex_ * mvd, dq = sc * ex_ * mdd;
+                const T val = sc * (mpd * gp + mvd * gv) + (lane == rho ? sc * mdd : (T)0);
+                T *dst = (lane <= rho && lane < n) ? colK + rho : xb + lane;
+                *dst = val;
+                // ---- advance the recursion to state s+1 -----------------------------------------------------------
+                const T A02 = q[0], A03 = q[1], A12 = q[2], A13 = q[3], A23 = q[4], Bdx = q[5], Bdy = q[6], Bdp = q[7];
+                gx += A02 * gp + A03 * gv;
+                gy += A12 * gp + A13 * gv;
+                gp += A23 * gv;
+                const bool isnew = (lane >> 1) == s;   // columns 2s, 2s+1 enter with B_s
+                gx = isnew ? Bdx * pef : gx;
+                gy = isnew ? Bdy * pef : gy;
+                gp = isnew ? Bdp * pef : gp;
+                gv = isnew ? gvnew : gv;
+                // weights of state s+1: 2Q_{s+1} + M_{s+1}^{psi,v}  (needs stage s+1's second-order scalars)
+                const T *q1 = lin + LIN_STRIDE * (s + 1 < N ? s + 1 : N - 1);
+                const T ex1 = s + 1 < N ? exs : (T)0;
+                const T mpp1 = ex1 * q1[8], mpv1 = ex1 * q1[9];
+                const T Cv1 = s + 1 <= N - 1 ? (T)2 * Cv : (T)0;
+                // component-major staging: opb[comp][col]
+                opb[0 * 64 + lane] = gx; opb[1 * 64 + lane] = gy; opb[2 * 64 + lane] = gp; opb[3 * 64 + lane] = gv;
+                opb[4 * 64 + lane] = (T)2 * Cx * gx;
+                opb[5 * 64 + lane] = (T)2 * Cy * gy;
+                opb[6 * 64 + lane] = ((T)2 * Cp + mpp1) * gp + mpv1 * gv;
+                opb[7 * 64 + lane] = Cv1 * gv + mpv1 * gp;
+                WFENCE();
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int col = 16 * t + c;
-                    const bool okw = kk == 0 && col <= rho;
-                    T *dst = okw ? Lc + offc_rt(okw ? col : 0) + rho : xb + lane;
-                    *dst = a * gps[t] + bq * gv[t] + (col == rho ? dq : (T)0);
-                }
+                for (int t = 0; t < NT; ++t) { fa[t] = opb[kk * 64 + 16 * t + c]; fb[t] = opb[(4 + kk) * 64 + 16 * t + c]; }
             }
-            cA = ncA; cB = ncB; bo = nbo; A23 = nA23; Bdp = nBdp;
-            mppl = nmppl; mpvl = nmpvl; mpd = nmpd; mvd = nmvd; mdd = nmdd;
         }
     }
 
@@ -441,37 +438,42 @@ template <typename T, int N> struct FastSolver {
     // One rolled elimination sweep over columns [j0, j1): lane i holds the live part of row i in
     // slot[] with the CURRENT pivot column at slot[0] (the array shifts one place per step, so all
     // register indices are static).  LEN = number of trailing entries that still matter.
-    template <int LEN> DEV void chol_sweep(T (&slot)[N], int j0, int j1, bool &ok)
+    // `l` enters holding column j0 of L (pivot already taken), and leaves holding column j1 (if any).
+    template <int LEN> DEV void chol_sweep(T (&slot)[N], int j0, int j1, T &l, bool &ok)
     {
 #pragma nounroll
         for (int j = j0; j < j1; ++j) {
-            const T d = readlane_(slot[0], j);
-            ok = ok && (d > Real<T>::tiny()) && (d < (T)1e300);
-            const T rinv = rsqrt_(d);
-            const T l = slot[0] * rinv;  // L[lane][j] (lanes < j hold garbage that nothing reads)
             const int oc = offc_rt(j);
             T *dst = (lane >= j && lane <= n) ? Lc + oc + lane : xb + lane;  // branch-free: others hit a dummy word
             *dst = l;                     // column j of L: broadcast source now, Schur / back-substitution input later
             WFENCE();
-            // rank-1 update: fetch ALL multipliers L[j+1+p][j] first (uniform-address LDS reads, issued back to
-            // back into registers), then the FMAs back to back -- no per-entry dependency stall
-            const T *pb = Lc + oc + j + 1;
-            T m[LEN];
+            // multipliers L[j+2+p][j] of the trailing entries: uniform-address LDS reads, all issued up front
+            const T *pb = Lc + oc + j + 2;
+            T m[LEN > 1 ? LEN - 1 : 1];
 #pragma unroll
-            for (int p = 0; p < LEN; ++p) m[p] = pb[p];
+            for (int p = 0; p + 1 < LEN; ++p) m[p] = pb[p];
+            // look-ahead: the NEXT pivot entry needs only registers -- its multiplier L[j+1][j] is lane j+1's own l --
+            // so the next column's rsqrt chain runs while the LDS broadcast above is still in flight
+            const T s0 = fma(-l, readlane_(l, j + 1 < 64 ? j + 1 : 63), slot[1]);
+            const T dn = readlane_(s0, j + 1 < 64 ? j + 1 : 63);
+            const T lnext = s0 * rsqrt_(dn);
+            if (j + 1 < j1 || j1 == 0) ok = ok && (dn > Real<T>::tiny()) && (dn < (T)1e300);
 #pragma unroll
-            for (int p = 0; p < LEN; ++p) slot[p] = fma(-l, m[p], slot[p + 1 < N ? p + 1 : N - 1]);
+            for (int p = 1; p < LEN; ++p) slot[p] = fma(-l, m[p - 1], slot[p + 1 < N ? p + 1 : N - 1]);
+            slot[0] = s0;
+            l = lnext;
+            if (!ok) return;  // indefinite: stop at the first bad pivot (wave-uniform)
         }
     }
 
-    // In-register Cholesky of the packed image + both substitutions; x (lane j) = K^{-1} rhs.
+    // In-register Cholesky of the packed image (row n carries a right-hand side, so L^{-1} rhs falls out).
     // Rows (and the rhs as row n) live one per lane.  Three rolled phases with h = N:
     //   1. columns 0..h-1      : every row holds its entries of columns 0..h-1
     //   2. Schur update        : rows h..n load their columns h..n-1 and subtract L21 L21^T
     //   3. columns h..n-1      : same sweep as phase 1
     // Column j of L is stored into its packed LDS slot as soon as it is final; the substitution
     // L^{-1} rhs falls out as row n.
-    DEV bool chol_solve(T &xout)
+    DEV bool factor()
     {
         constexpr int h = N;
         static_assert(N % 4 == 0 && N >= 8, "rolled Cholesky assumes N % 4 == 0");
@@ -480,8 +482,16 @@ template <typename T, int N> struct FastSolver {
         bool ok = true;
 #pragma unroll
         for (int e = 0; e < h; ++e) slot[e] = Lc[offc(e) + lane];
-        chol_sweep<L1>(slot, 0, h / 2, ok);
-        chol_sweep<L2>(slot, h / 2, h, ok);
+        T lcol;
+        {
+            const T d0 = readlane_(slot[0], 0);
+            ok = ok && (d0 > Real<T>::tiny()) && (d0 < (T)1e300);
+            lcol = slot[0] * rsqrt_(d0);
+        }
+        chol_sweep<L1>(slot, 0, h / 2, lcol, ok);
+        if (ok) chol_sweep<L2>(slot, h / 2, h, lcol, ok);
+        if (!ok) return false;
+        STAMP(12);
         WFENCE();
         // ---- phase 2: trailing block (rows h..n incl. the rhs row, columns h..n-1) -= L21 L21^T on the
         // matrix cores.  L21[i][j] (i >= h, j < h) sits in the packed LDS columns; for the 16x16x4 MFMA both
@@ -520,28 +530,55 @@ template <typename T, int N> struct FastSolver {
                     }
         }
         WFENCE();
+        STAMP(13);
 #pragma unroll
         for (int e = 0; e < h; ++e) slot[e] = Lc[offc(h + e) + lane];
-        chol_sweep<L1>(slot, h, h + h / 2, ok);
-        chol_sweep<L2>(slot, h + h / 2, n, ok);
+        {
+            const T d0 = readlane_(slot[0], h);
+            ok = ok && (d0 > Real<T>::tiny()) && (d0 < (T)1e300);
+            lcol = slot[0] * rsqrt_(d0);
+        }
+        chol_sweep<L1>(slot, h, h + h / 2, lcol, ok);
+        chol_sweep<L2>(slot, h + h / 2, n, lcol, ok);
+        STAMP(14);
         if (!ok) return false;
         WFENCE();
-        // backward substitution L^T x = y: lane j < n owns column j; blocks of 8 register-resident entries
-        const int jl = lane < n ? lane : 0;
-        const T *pc = Lc + offc_rt(jl);
-        T sacc = lane < n ? pc[n] : (T)0;
-        const T dinv = lane < n ? (T)1 / pc[jl] : (T)0;
+        dinv_l = lane < n ? (T)1 / Lc[offc_rt(lane) + lane] : (T)0;  // 1 / L[lane][lane]
+        return true;
+    }
+
+    // Triangular substitutions on the packed factor (lane j <-> component j).  Columns are pre-scaled by the
+    // owner's 1/L_jj off the critical path, so the dependent chain per step is just v_readlane + FMA.
+    DEV T fwd_subst(T b)  // solves L y = b
+    {
+        T wv = b * dinv_l;
+#pragma nounroll
+        for (int blk = 0; blk < n / 8; ++blk) {
+            T cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = 8 * blk + u;
+                const T v = Lc[offc_rt(j) + lane];  // L[lane][j]
+                cv[u] = (lane > j && lane < n) ? v * dinv_l : (T)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv = fma(-cv[u], readlane_(wv, 8 * blk + u), wv);
+        }
+        return wv;
+    }
+    DEV T back_subst(T y)  // solves L^T x = y
+    {
+        const T *pc = Lc + offc_rt(lane < n ? lane : 0);
+        T wv = y * dinv_l;
 #pragma nounroll
         for (int blk = n / 8 - 1; blk >= 0; --blk) {
             T cv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = 8 * blk + u; const T v = pc[i]; cv[u] = (i > lane && lane < n) ? v : (T)0; }
+            for (int u = 0; u < 8; ++u) { const int i = 8 * blk + u; const T v = pc[i]; cv[u] = (i > lane && lane < n) ? v * dinv_l : (T)0; }
 #pragma unroll
-            for (int u = 7; u >= 0; --u) { const T xi = readlane_(sacc * dinv, 8 * blk + u); sacc = fma(-cv[u], xi, sacc); }
+            for (int u = 7; u >= 0; --u) wv = fma(-cv[u], readlane_(wv, 8 * blk + u), wv);
         }
-        xout = sacc * dinv;
-        WSYNC();
-        return true;
+        return wv;
     }
 
     DEV bool interior_point(T &Uf)
@@ -592,12 +629,17 @@ template <typename T, int N> struct FastSolver {
         bool fv[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i]); lu[i] = ll[i] = au[i] = aut[i] = (T)0; }
-        int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0;
+        int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
         T err_last = (T)1e30, Ubest = 0;
         bool have_best = false;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, Jt = 0, alpha = 0, ad = 0, phi0 = 0, dphi = 0, reg = 0;
         bool use_exact = exact;
-        enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3 };
+        enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3, RESTEP = 4 };
+        const bool pc = P.mu_strategy == 1;
+        T corru[NF], corrl[NF], ya = 0, mu_floor = 0;
+        bool corr_active = false;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
         int mode = FIRST;
         StageF<T> St;
         STAMP_DECL
@@ -634,7 +676,7 @@ template <typename T, int N> struct FastSolver {
                 // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
                 Ut = Ubest; U = Ubest; status = 0;
             }
-            Jt = eval(Ut, St);
+            if (mode != REFACTOR) Jt = eval(Ut, St);  // a refactor pass re-uses the evaluation and the stage scalars of U
             STAMP(9);
             if (mode == FINAL) break;
             if (mode == TRIAL) {
@@ -649,7 +691,10 @@ template <typename T, int N> struct FastSolver {
                 okp = __all(okp);
                 const T phi = sc * Jt - mu * dpp_sum(lgt);
                 if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi)) {
-                    if (++ls >= P.max_ls) { status = err_last <= (T)100 * tol ? 0 : 3; mode = FINAL; Ut = U; continue; }  // acceptable level
+                    if (++ls >= P.max_ls) {
+                        if (corr_active) { mode = RESTEP; Ut = U; continue; }  // safeguard: redo the step without the corrector term
+                        status = err_last <= (T)100 * tol ? 0 : 3; mode = FINAL; Ut = U; continue;  // acceptable level
+                    }
                     alpha *= (T)0.5;
                     Ut = U + alpha * du;
                     continue;
@@ -659,14 +704,16 @@ template <typename T, int N> struct FastSolver {
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
                         const T su = bu[i] - au[i], sl = bl[i] + au[i];
-                        lu[i] += ad * ((mu - lu[i] * su) / su + lu[i] / su * aut[i]);
-                        ll[i] += ad * ((mu - ll[i] * sl) / sl - ll[i] / sl * aut[i]);
+                        lu[i] += ad * ((mu - corru[i] - lu[i] * su) / su + lu[i] / su * aut[i]);
+                        ll[i] += ad * ((mu - corrl[i] - ll[i] * sl) / sl - ll[i] / sl * aut[i]);
                     }
             }
-            U = Ut; J = Jt;
-            g = linearize(St, use_exact);
-            STAMP(1);
+            const bool restep = mode == RESTEP;
+            if (!restep) {
             if (mode != REFACTOR) {
+            U = Ut; J = Jt;
+            g = linearize(St, exact);
+            STAMP(1);
                 forms_apply(U, au);
                 if (mode == FIRST) {
                     const T gm = dpp_max(fabs(g));
@@ -711,8 +758,9 @@ template <typename T, int N> struct FastSolver {
                 n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
                 if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
                 const T mu_min = fmax(tol * (T)1e-2, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
+                mu_floor = mu_min;
 #pragma nounroll
-                for (;;) {  // monotone barrier update
+                for (; !pc;) {  // monotone barrier update (mu_strategy 0)
                     T cmu = 0;
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
@@ -721,13 +769,12 @@ template <typename T, int N> struct FastSolver {
                     if (fmax(rdm, cmu) / s_d <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, mu * sqrt(mu)));
                     else break;
                 }
-                use_exact = exact; reg = 0; attempt = 0;
+                use_exact = exact && gn_hold == 0; reg = 0; attempt = 0;  // GN is held for 2 iterations after an indefinite exact Hessian
+                if (gn_hold > 0) --gn_hold;
                 STAMP(2);
             }
-            // rhs = -(sc*g + A^T(mu/s_u - mu/s_l)); form weights for A^T Sigma A
-#pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -(mu / (bu[i] - au[i]) - mu / (bl[i] + au[i])) : (T)0;
-            rhs = -sc * g + forms_applyT(w);
+            // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
+            rhs = -sc * g;
 #pragma unroll
             for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / (bu[i] - au[i]) + ll[i] / (bl[i] + au[i]) : (T)0;
             stage_form_weights(w);
@@ -740,25 +787,71 @@ template <typename T, int N> struct FastSolver {
                 build_K(acc, sc, reg, rhs);
                 STAMP(4);
             }
-            factored = chol_solve(du);
+            factored = factor();
             STAMP(5);
             if (!factored) {
                 if (++attempt >= 14) { status = 3; mode = FINAL; Ut = U; continue; }
-                if (use_exact) { use_exact = false; mode = REFACTOR; Ut = U; continue; }  // drop the second-order term first
+                if (use_exact) { use_exact = false; gn_hold = 2; mode = REFACTOR; Ut = U; continue; }  // drop the second-order term first
                 reg = reg == 0 ? (T)1e-8 : reg * (T)100;                                   // then delta_w escalation
                 mode = REFACTOR; Ut = U;
                 continue;
             }
+            ya = lane < n ? Lc[offc_rt(lane) + n] : (T)0;  // L^{-1}(-sc*g)
+#pragma unroll
+            for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
+            corr_active = false;
+            if (pc) {
+                // Mehrotra predictor: affine-scaling step on the same factor -> this iteration's barrier target
+                const T dua = back_subst(ya);
+                forms_apply(dua, aut);
+                T apa = 1, ada = 1, mucur = 0, muaff = 0;
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        const T su = bu[i] - au[i], sl = bl[i] + au[i], dsu = -aut[i], dsl = aut[i];
+                        const T dlu = -lu[i] - lu[i] / su * dsu, dll = -ll[i] - ll[i] / sl * dsl;
+                        if (dsu < 0) apa = fmin(apa, -su / dsu);
+                        if (dsl < 0) apa = fmin(apa, -sl / dsl);
+                        if (dlu < 0) ada = fmin(ada, -lu[i] / dlu);
+                        if (dll < 0) ada = fmin(ada, -ll[i] / dll);
+                        mucur += su * lu[i] + sl * ll[i];
+                    }
+                apa = dpp_min(apa); ada = dpp_min(ada);
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                    if (fv[i]) {
+                        const T su = bu[i] - au[i], sl = bl[i] + au[i], dsu = -aut[i], dsl = aut[i];
+                        const T dlu = -lu[i] - lu[i] / su * dsu, dll = -ll[i] - ll[i] / sl * dsl;
+                        muaff += (su + apa * dsu) * (lu[i] + ada * dlu) + (sl + apa * dsl) * (ll[i] + ada * dll);
+                        corru[i] = dsu * dlu; corrl[i] = dsl * dll;
+                    }
+                mucur = dpp_sum(mucur) / (T)(2 * nf); muaff = dpp_sum(muaff) / (T)(2 * nf);
+                const T r3 = muaff / mucur;
+                mu = fmax(mu_floor, fmin((T)1, r3 * r3 * r3) * mucur);
+                corr_active = true;
+                STAMP(7);
+            }
+            } else {  // RESTEP: same factor, corrector term dropped
+#pragma unroll
+                for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
+                corr_active = false;
+            }
+            // centering (+ corrector) part of the step: du = K^{-1}(-sc*g - A^T((mu - corr)/s_u - (mu - corr)/s_l))
+#pragma unroll
+            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - corru[i]) / (bu[i] - au[i]) - (mu - corrl[i]) / (bl[i] + au[i])) : (T)0;
+            du = back_subst(ya + fwd_subst(forms_applyT(w)));
+            STAMP(15);
             forms_apply(du, aut);
             const T tau = fmax(tau_min, (T)1 - mu);
-            T ap = 1, lg = 0;
+            T ap = 1, lg = 0, gw = 0;
             ad = 1;
 #pragma unroll
             for (int i = 0; i < NF; ++i)
                 if (fv[i]) {
                     const T su = bu[i] - au[i], sl = bl[i] + au[i], dsu = -aut[i], dsl = aut[i];
-                    const T dlu = (mu - lu[i] * su) / su - lu[i] / su * dsu;
-                    const T dll = (mu - ll[i] * sl) / sl - ll[i] / sl * dsl;
+                    const T dlu = (mu - corru[i] - lu[i] * su) / su - lu[i] / su * dsu;
+                    const T dll = (mu - corrl[i] - ll[i] * sl) / sl - ll[i] / sl * dsl;
+                    gw += (mu / su - mu / sl) * aut[i];
                     if (dsu < 0) ap = fmin(ap, -tau * su / dsu);
                     if (dsl < 0) ap = fmin(ap, -tau * sl / dsl);
                     if (dlu < 0) ad = fmin(ad, -tau * lu[i] / dlu);
@@ -767,7 +860,7 @@ template <typename T, int N> struct FastSolver {
                 }
             ap = dpp_min(ap); ad = dpp_min(ad);
             phi0 = sc * J - mu * dpp_sum(lg);
-            dphi = dpp_sum(lane < n ? -rhs * du : (T)0);
+            dphi = dpp_sum((lane < n ? sc * g * du : (T)0) + gw);  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
             alpha = ap; ls = 0;
             Ut = U + alpha * du;
             mode = TRIAL;

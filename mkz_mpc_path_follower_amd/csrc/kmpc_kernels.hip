@@ -35,6 +35,7 @@ template <typename T, int NT> struct Solver {
     static constexpr int NTT = NT * (NT + 1) / 2;        // lower-triangular tiles
     typedef typename Real<T>::acc_t acc_t;
 
+    STAMP_MEMBERS
     const KP &P;
     const int lane, N, n, R, nf, ld;
     T *Km, *stg, *xb, *wb, *cb, *dinv;
@@ -456,7 +457,8 @@ template <typename T, int NT> struct Solver {
         bool fv[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i], rlx[i]); }
-        int status = 1, iters = 0, n_polish = 0, n_accept = 0;
+        int status = 1, iters = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
+        T dw_last = 0;
         bool have_best = false;
         T Ubest[NV];
 #pragma unroll
@@ -551,7 +553,7 @@ template <typename T, int NT> struct Solver {
                 n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
                 if (n_accept >= 15) { status = 0; break; }
                 const T mu_min = fmax(tol * (T)1e-2, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
-                for (;;) {  // monotone barrier update
+                for (; P.mu_strategy == 0;) {  // monotone barrier update (Ipopt default); mu_strategy 1 picks mu after the predictor
                     T cmu = 0;
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
@@ -561,80 +563,144 @@ template <typename T, int NT> struct Solver {
                         mu = fmax(mu_min, fmin(kappa_mu * mu, pow(mu, theta_mu)));
                     else break;
                 }
-                const T tau = fmax(tau_min, (T)1 - mu);
                 STAMP(2);
                 // factor K = sc*H + A^T Sigma A
 #pragma unroll
                 for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / su[i] + ll[i] / sl[i] : (T)0;
-                bool use_exact = exact;
-                T reg = 0;
-                bool factored = false;
-                for (int attempt = 0; attempt < 14; ++attempt) {
-                    if (attempt <= 1) condense(use_exact, acc);
+                bool use_exact = exact && gn_hold == 0;  // GN is held for 2 iterations after an indefinite exact Hessian
+                if (gn_hold > 0) --gn_hold;
+                // Indefinite exact Hessian: indef_strategy 0 -> Gauss-Newton for this and the next 2 iterations;
+                // 1 -> Ipopt's inertia correction, K + delta_w*I with delta_w = 1e-4*max|sc*H_jj| (x100) the first time,
+                // last/3 (x8) afterwards; the accumulators are kept, so a retry is one build_K + one factorisation.
+                T reg = 0, hmax = 0;
+                bool factored = false, need_condense = true;
+                for (int attempt = 0; attempt < 40; ++attempt) {
+                    if (need_condense) {
+                        condense(use_exact, acc);
+                        need_condense = false;
+                        if (P.indef_strategy == 1 && use_exact) {  // max |sc * H_jj| over the diagonal of the tiles
+                            T hm = 0;
+#pragma unroll
+                            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[ti * (ti + 1) / 2 + ti][r]));
+                            hmax = wave_max(hm);
+                        }
+                    }
                     STAMP(3);
                     stage_form_weights(w);
                     build_K(acc, sc, reg);
                     STAMP(4);
                     const bool okc = cholesky();
                     STAMP(5);
-                    if (okc) { factored = true; break; }
-                    if (use_exact) use_exact = false;            // drop the second-order term first
-                    else reg = reg == 0 ? (T)1e-8 : reg * (T)100;  // then delta_w escalation
+                    if (okc) { factored = true; if (use_exact && reg > 0) dw_last = reg; break; }
+                    if (use_exact && P.indef_strategy == 1) {
+                        if (reg == 0) reg = dw_last > 0 ? fmax((T)1e-10 * hmax, dw_last / 3) : (T)1e-4 * hmax;
+                        else reg *= dw_last > 0 ? (T)8 : (T)100;
+                        if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; need_condense = true; }
+                    } else if (use_exact) { use_exact = false; gn_hold = 2; need_condense = true; }  // drop the second-order term
+                    else reg = reg == 0 ? (T)1e-8 : reg * (T)100;  // last resort: shift the Gauss-Newton matrix
                 }
                 if (!factored) { status = 3; break; }
-                // rhs = -(sc*g + A^T(mu/s_u - mu/s_l))
+                // Mehrotra predictor-corrector (mu_strategy 1): affine-scaling step on the same factor -> barrier
+                // target mu = sigma*mu_cur, sigma = (mu_aff/mu_cur)^3, and the second-order complementarity term
+                T corru[NF], corrl[NF];
 #pragma unroll
-                for (int i = 0; i < NV; ++i) rhs[i] = -sc * g[i];
+                for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
+                if (P.mu_strategy == 1) {
 #pragma unroll
-                for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -(mu / su[i] - mu / sl[i]) : (T)0;
-                forms_applyT_add(w, rhs);
-#pragma unroll
-                for (int i = 0; i < NV; ++i) du[i] = rhs[i];
-                STAMP(6);
-                chol_solve(du);
-                STAMP(7);
-                forms_apply(du, aut);
-                T ap = 1, ad = 1;
-#pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    dlu[i] = dll[i] = 0;
-                    if (fv[i]) {
-                        const T dsu = -aut[i], dsl = aut[i];
-                        dlu[i] = (mu - lu[i] * su[i]) / su[i] - lu[i] / su[i] * dsu;
-                        dll[i] = (mu - ll[i] * sl[i]) / sl[i] - ll[i] / sl[i] * dsl;
-                        if (dsu < 0) ap = fmin(ap, -tau * su[i] / dsu);
-                        if (dsl < 0) ap = fmin(ap, -tau * sl[i] / dsl);
-                        if (dlu[i] < 0) ad = fmin(ad, -tau * lu[i] / dlu[i]);
-                        if (dll[i] < 0) ad = fmin(ad, -tau * ll[i] / dll[i]);
-                    }
-                }
-                ap = wave_min(ap); ad = wave_min(ad);
-                T lg = 0, dphi = 0;
-#pragma unroll
-                for (int i = 0; i < NF; ++i) if (fv[i]) lg += log(su[i]) + log(sl[i]);
-#pragma unroll
-                for (int i = 0; i < NV; ++i) dphi -= rhs[i] * du[i];
-                const T phi0 = sc * J - mu * wave_sum(lg);
-                dphi = wave_sum(dphi);
-                STAMP(8);
-                T alpha = ap, Jt = 0;
-                bool accepted = false;
-                for (int l = 0; l < P.max_ls; ++l, alpha *= (T)0.5) {
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) Ut[i] = U[i] + alpha * du[i];
-                    Jt = eval(Ut, St);
-                    forms_apply(Ut, au);
-                    T lgt = 0;
-                    bool ok = true;
+                    for (int i = 0; i < NV; ++i) du[i] = -sc * g[i];
+                    chol_solve(du);
+                    forms_apply(du, aut);
+                    T apa = 1, ada = 1, mucur = 0, muaff = 0;
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
                         if (fv[i]) {
-                            const T a_ = bu[i] - au[i], b_ = bl[i] + au[i];
-                            if (!(a_ > 0) || !(b_ > 0)) ok = false; else lgt += log(a_) + log(b_);
+                            const T dsu = -aut[i], dsl = aut[i];
+                            const T dlu_ = -lu[i] - lu[i] / su[i] * dsu, dll_ = -ll[i] - ll[i] / sl[i] * dsl;
+                            if (dsu < 0) apa = fmin(apa, -su[i] / dsu);
+                            if (dsl < 0) apa = fmin(apa, -sl[i] / dsl);
+                            if (dlu_ < 0) ada = fmin(ada, -lu[i] / dlu_);
+                            if (dll_ < 0) ada = fmin(ada, -ll[i] / dll_);
+                            mucur += su[i] * lu[i] + sl[i] * ll[i];
                         }
-                    ok = __all(ok);
-                    const T phi = sc * Jt - mu * wave_sum(lgt);
-                    if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; break; }
+                    apa = wave_min(apa); ada = wave_min(ada);
+#pragma unroll
+                    for (int i = 0; i < NF; ++i)
+                        if (fv[i]) {
+                            const T dsu = -aut[i], dsl = aut[i];
+                            const T dlu_ = -lu[i] - lu[i] / su[i] * dsu, dll_ = -ll[i] - ll[i] / sl[i] * dsl;
+                            muaff += (su[i] + apa * dsu) * (lu[i] + ada * dlu_) + (sl[i] + apa * dsl) * (ll[i] + ada * dll_);
+                            corru[i] = dsu * dlu_; corrl[i] = dsl * dll_;
+                        }
+                    mucur = wave_sum(mucur) / (T)(2 * nf); muaff = wave_sum(muaff) / (T)(2 * nf);
+                    const T r3 = muaff / mucur;
+                    mu = fmax(mu_min, fmin((T)1, r3 * r3 * r3) * mucur);
+                }
+                const T tau = fmax(tau_min, (T)1 - mu);
+                T ad = 1, Jt = 0;
+                bool accepted = false;
+                for (int pass = 0; pass < 2 && !accepted; ++pass) {
+                    if (pass == 1) {  // safeguard: the corrected direction need not be a descent direction -> drop the corrector
+                        if (P.mu_strategy != 1) break;
+#pragma unroll
+                        for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) rhs[i] = -sc * g[i];
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - corru[i]) / su[i] - (mu - corrl[i]) / sl[i]) : (T)0;
+                    forms_applyT_add(w, rhs);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) du[i] = rhs[i];
+                    STAMP(6);
+                    chol_solve(du);
+                    STAMP(7);
+                    forms_apply(du, aut);
+                    T ap = 1, gw = 0;
+                    ad = 1;
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) {
+                        dlu[i] = dll[i] = 0;
+                        if (fv[i]) {
+                            const T dsu = -aut[i], dsl = aut[i];
+                            dlu[i] = (mu - corru[i] - lu[i] * su[i]) / su[i] - lu[i] / su[i] * dsu;
+                            dll[i] = (mu - corrl[i] - ll[i] * sl[i]) / sl[i] - ll[i] / sl[i] * dsl;
+                            gw += (mu / su[i] - mu / sl[i]) * aut[i];
+                            if (dsu < 0) ap = fmin(ap, -tau * su[i] / dsu);
+                            if (dsl < 0) ap = fmin(ap, -tau * sl[i] / dsl);
+                            if (dlu[i] < 0) ad = fmin(ad, -tau * lu[i] / dlu[i]);
+                            if (dll[i] < 0) ad = fmin(ad, -tau * ll[i] / dll[i]);
+                        }
+                    }
+                    ap = wave_min(ap); ad = wave_min(ad);
+                    T lg = 0, dphi = gw;  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) if (fv[i]) lg += log(su[i]) + log(sl[i]);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) dphi += sc * g[i] * du[i];
+                    const T phi0 = sc * J - mu * wave_sum(lg);
+                    dphi = wave_sum(dphi);
+                    STAMP(8);
+                    T alpha = ap;
+                    for (int l = 0; l < P.max_ls; ++l, alpha *= (T)0.5) {
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) Ut[i] = U[i] + alpha * du[i];
+                        Jt = eval(Ut, St);
+                        forms_apply(Ut, au);
+                        T lgt = 0;
+                        bool ok = true;
+#pragma unroll
+                        for (int i = 0; i < NF; ++i)
+                            if (fv[i]) {
+                                const T a_ = bu[i] - au[i], b_ = bl[i] + au[i];
+                                if (!(a_ > 0) || !(b_ > 0)) ok = false; else lgt += log(a_) + log(b_);
+                            }
+                        ok = __all(ok);
+                        const T phi = sc * Jt - mu * wave_sum(lgt);
+                        if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; break; }
+                    }
                 }
                 STAMP(9);
                 if (!accepted) { status = err0 <= (T)100 * tol ? 0 : 3; break; }  // acceptable level reached

@@ -19,6 +19,8 @@ void kmpc_opts_default(kmpc_opts *o)
     o->warm_push = 0.01;
     o->warm_mu = 1e-3;
     o->max_ls = 40;
+    o->mu_strategy = -1;
+    o->indef_strategy = -1;
 }
 
 /* ---- "forms": the 5N-2 distinct linear forms a_f^T U behind the 10N-4 one-sided rows.
@@ -339,12 +341,17 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc
     double *bu = tmpn + 5 * n, *bl = bu + nf, *su = bl + nf, *sl = su + nf, *lu = sl + nf, *ll = lu + nf,
            *au = ll + nf, *dlu = au + nf, *dll = dlu + nf, *w = dll + nf, *aut = w + nf, *w2 = aut + nf;
     double *Xl = w2 + 2 * nf, *Xt = Xl + (N + 1) * 4;
-    int status = KMPC_ITERATION_LIMIT, iters = 0, n_refac = 0, n_ls = 0;
+    int status = KMPC_ITERATION_LIMIT, iters = 0, n_refac = 0, n_ls = 0, n_solves = 0;
+    /* barrier strategy: -1 = default by horizon (Mehrotra validated for N <= 24; longer horizons keep Ipopt's monotone rule) */
+    const int mu_strategy = o->mu_strategy >= 0 ? o->mu_strategy : (N <= 24 ? 1 : 0);
     double mu = o->warm ? o->warm_mu : o->mu_init, err0 = INFINITY, sc = 1.0, J = 0.0;
     const double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, kappa_sigma = 1e10,
                  eta_phi = 1e-8, s_max = 100.0;
     const double gap_tol = 1e-7;
     const int max_polish = 1;
+    int gn_hold = 0;
+    double dw_last = 0.0;
+    const int indef_strategy = o->indef_strategy >= 0 ? o->indef_strategy : (N <= 24 ? 0 : 1);
     int have_best = 0;
     double *Ubest = (double *)malloc((size_t)(n + 2 * nf) * sizeof(double));
     int n_polish = 0, n_accept = 0;
@@ -426,7 +433,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc
         if (n_accept >= 15) { status = KMPC_OPTIMAL; break; }
         const double mu_min = fmax(o->tol * 1e-2, fmin(o->tol / 10.0, 0.1 * gap_lim * sc / (2.0 * nf)));
         /* monotone barrier update (Ipopt eq. (7)) */
-        for (;;) {
+        for (; mu_strategy == 0;) {
             double cmu = 0.0;
             for (int f = 0; f < nf; ++f)
                 cmu = fmax(cmu, fmax(fabs(su[f] * lu[f] - mu), fabs(sl[f] * ll[f] - mu)));
@@ -434,58 +441,114 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc
             if (errmu <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, pow(mu, theta_mu)));
             else break;
         }
-        const double tau = fmax(tau_min, 1.0 - mu);
         /* K = sc*H + A^T Sigma A ; rhs = -(sc*g + A^T(mu/s_u - mu/s_l)) */
-        int use_gn = (o->hessian != 1);
-        double reg = 0.0;
+        /* Indefinite exact Hessian (K not positive definite):
+           indef_strategy 0: drop the second-order terms (Gauss-Newton) for this and the next gn_hold_k iterations
+                             (a failed factorisation costs as much as a good one; N = 20: 11.1 -> 10.2 factorisations per solve);
+           indef_strategy 1: Ipopt's inertia correction -- shift the exact Hessian by delta_w*I, delta_w = 1e-4*max|H_jj| the first
+                             time (x100 on failure), later last/3 (x8 on failure); Gauss-Newton only if the shift exceeds 1e2*max|H_jj|.
+           Short horizons do better with 0, long ones (N = 50: <= 28 iterations instead of 100-190) with 1. */
+        const int gn_hold_k = 2;
+        int use_gn = (o->hessian != 1) || gn_hold > 0;
+        if (gn_hold > 0) --gn_hold;
+        double reg = 0.0, hmax = 0.0;
+        for (int j = 0; j < n; ++j) hmax = fmax(hmax, fabs(sc * H[j * n + j]));
         for (int attempt = 0;; ++attempt) {
             const double *Hs = use_gn ? Hgn : H;
             for (int i = 0; i < n * n; ++i) K[i] = sc * Hs[i];
             for (int f = 0; f < nf; ++f) w[f] = lu[f] / su[f] + ll[f] / sl[f];
             forms_gram_add(&F, w, K);
             for (int j = 0; j < n; ++j) K[j * n + j] += reg;
-            if (chol(K, n) == 0) break;
+            if (chol(K, n) == 0) { if (!use_gn && reg > 0.0) dw_last = reg; break; }
             ++n_refac;
-            if (!use_gn) use_gn = 1;                    /* drop the second-order term first */
-            else reg = reg == 0.0 ? 1e-8 : reg * 100.0; /* then Ipopt-like delta_w escalation */
-            if (attempt > 12) { status = KMPC_NUMERICAL_ERROR; goto finish; }
+            if (!use_gn && indef_strategy == 1) {
+                if (reg == 0.0) reg = dw_last > 0.0 ? fmax(1e-10 * hmax, dw_last / 3.0) : 1e-4 * hmax;
+                else reg *= (dw_last > 0.0 ? 8.0 : 100.0);
+                if (reg > 1e2 * hmax) { use_gn = 1; reg = 0.0; }
+            } else if (!use_gn) { use_gn = 1; gn_hold = gn_hold_k; }
+            else reg = reg == 0.0 ? 1e-8 : reg * 100.0; /* last resort: shift the Gauss-Newton matrix */
+            if (attempt > 40) { status = KMPC_NUMERICAL_ERROR; goto finish; }
         }
-        for (int j = 0; j < n; ++j) rhs[j] = -sc * g[j];
-        for (int f = 0; f < nf; ++f) w[f] = -(mu / su[f] - mu / sl[f]);
-        forms_applyT_add(&F, w, rhs);
-        memcpy(du, rhs, (size_t)n * sizeof(double));
-        chol_solve(K, n, du);
-        forms_apply(&F, du, aut); /* a_f^T du ; ds_u = -aut, ds_l = +aut */
-        double ap = 1.0, ad = 1.0;
-        for (int f = 0; f < nf; ++f) {
-            const double dsu = -aut[f], dsl = aut[f];
-            dlu[f] = (mu - lu[f] * su[f]) / su[f] - lu[f] / su[f] * dsu;
-            dll[f] = (mu - ll[f] * sl[f]) / sl[f] - ll[f] / sl[f] * dsl;
-            if (dsu < 0.0) ap = fmin(ap, -tau * su[f] / dsu);
-            if (dsl < 0.0) ap = fmin(ap, -tau * sl[f] / dsl);
-            if (dlu[f] < 0.0) ad = fmin(ad, -tau * lu[f] / dlu[f]);
-            if (dll[f] < 0.0) ad = fmin(ad, -tau * ll[f] / dll[f]);
-        }
-        /* Armijo on phi_mu(U) = sc*J(U) - mu*sum log s  along du */
-        double phi0 = sc * J, dphi = 0.0;
-        for (int f = 0; f < nf; ++f) phi0 -= mu * (log(su[f]) + log(sl[f]));
-        for (int j = 0; j < n; ++j) dphi -= rhs[j] * du[j]; /* grad phi = -rhs */
-        double alpha = ap;
-        int accepted = 0;
-        for (int l = 0; l < o->max_ls; ++l, alpha *= 0.5) {
-            ++n_ls;
-            for (int j = 0; j < n; ++j) Ut[j] = U[j] + alpha * du[j];
-            kmpc_rollout(p, q->z0, Ut, Xt);
-            double phi = sc * kmpc_cost(p, q, Ut, Xt);
-            forms_apply(&F, Ut, w2);
-            int ok = 1;
+        /* Mehrotra predictor-corrector (mu_strategy 1; Ipopt's "adaptive mu" family): the affine-scaling step
+           (target mu = 0) on the same factorisation probes how much of the complementarity can be removed;
+           sigma = (mu_aff/mu_cur)^3 sets this iteration's barrier target, and the second-order term
+           ds_aff*dlam_aff corrects the complementarity linearisation. */
+        double *corru = tmpn, *corrl = tmpn + nf;  /* 2 nf <= 5 n */
+        for (int f = 0; f < nf; ++f) corru[f] = corrl[f] = 0.0;
+        if (mu_strategy == 1) {
+            for (int j = 0; j < n; ++j) du[j] = -sc * g[j];
+            chol_solve(K, n, du);
+            ++n_solves;
+            forms_apply(&F, du, aut);
+            double apa = 1.0, ada = 1.0, mucur = 0.0, muaff = 0.0;
             for (int f = 0; f < nf; ++f) {
-                const double a = bu[f] - w2[f], b = bl[f] + w2[f];
-                if (!(a > 0.0) || !(b > 0.0)) { ok = 0; break; }
-                phi -= mu * (log(a) + log(b));
+                const double dsu = -aut[f], dsl = aut[f];
+                const double dlu_ = -lu[f] - lu[f] / su[f] * dsu, dll_ = -ll[f] - ll[f] / sl[f] * dsl;
+                if (dsu < 0.0) apa = fmin(apa, -su[f] / dsu);
+                if (dsl < 0.0) apa = fmin(apa, -sl[f] / dsl);
+                if (dlu_ < 0.0) ada = fmin(ada, -lu[f] / dlu_);
+                if (dll_ < 0.0) ada = fmin(ada, -ll[f] / dll_);
+                mucur += su[f] * lu[f] + sl[f] * ll[f];
             }
-            /* small slack for round-off as in Ipopt (10 * eps * |phi|) */
-            if (ok && phi - phi0 - 10.0 * 2.2e-16 * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = 1; break; }
+            for (int f = 0; f < nf; ++f) {
+                const double dsu = -aut[f], dsl = aut[f];
+                const double dlu_ = -lu[f] - lu[f] / su[f] * dsu, dll_ = -ll[f] - ll[f] / sl[f] * dsl;
+                muaff += (su[f] + apa * dsu) * (lu[f] + ada * dlu_) + (sl[f] + apa * dsl) * (ll[f] + ada * dll_);
+                corru[f] = dsu * dlu_;
+                corrl[f] = dsl * dll_;
+            }
+            mucur /= 2.0 * nf;
+            muaff /= 2.0 * nf;
+            const double r3 = muaff / mucur, sigma = fmin(1.0, r3 * r3 * r3);
+            mu = fmax(mu_min, sigma * mucur);
+        }
+        const double tau = fmax(tau_min, 1.0 - mu);
+        int accepted = 0;
+        double alpha = 0.0, ap = 1.0, ad = 1.0;
+        for (int pass = 0; pass < 2 && !accepted; ++pass) {
+            if (pass == 1) { /* safeguard: the corrected direction need not be a descent direction of phi_mu -> drop the corrector */
+                if (mu_strategy != 1) break;
+                for (int f = 0; f < nf; ++f) corru[f] = corrl[f] = 0.0;
+            }
+            for (int j = 0; j < n; ++j) rhs[j] = -sc * g[j];
+            for (int f = 0; f < nf; ++f) w[f] = -((mu - corru[f]) / su[f] - (mu - corrl[f]) / sl[f]);
+            forms_applyT_add(&F, w, rhs);
+            memcpy(du, rhs, (size_t)n * sizeof(double));
+            chol_solve(K, n, du);
+            ++n_solves;
+            forms_apply(&F, du, aut); /* a_f^T du ; ds_u = -aut, ds_l = +aut */
+            ap = 1.0; ad = 1.0;
+            double gw = 0.0;
+            for (int f = 0; f < nf; ++f) {
+                const double dsu = -aut[f], dsl = aut[f];
+                dlu[f] = (mu - corru[f] - lu[f] * su[f]) / su[f] - lu[f] / su[f] * dsu;
+                dll[f] = (mu - corrl[f] - ll[f] * sl[f]) / sl[f] - ll[f] / sl[f] * dsl;
+                gw += (mu / su[f] - mu / sl[f]) * aut[f];
+                if (dsu < 0.0) ap = fmin(ap, -tau * su[f] / dsu);
+                if (dsl < 0.0) ap = fmin(ap, -tau * sl[f] / dsl);
+                if (dlu[f] < 0.0) ad = fmin(ad, -tau * lu[f] / dlu[f]);
+                if (dll[f] < 0.0) ad = fmin(ad, -tau * ll[f] / dll[f]);
+            }
+            /* Armijo on phi_mu(U) = sc*J(U) - mu*sum log s along du; d phi/d alpha = (sc*g + A^T(mu/s_u - mu/s_l))^T du */
+            double phi0 = sc * J, dphi = gw;
+            for (int f = 0; f < nf; ++f) phi0 -= mu * (log(su[f]) + log(sl[f]));
+            for (int j = 0; j < n; ++j) dphi += sc * g[j] * du[j];
+            alpha = ap;
+            for (int l = 0; l < o->max_ls; ++l, alpha *= 0.5) {
+                ++n_ls;
+                for (int j = 0; j < n; ++j) Ut[j] = U[j] + alpha * du[j];
+                kmpc_rollout(p, q->z0, Ut, Xt);
+                double phi = sc * kmpc_cost(p, q, Ut, Xt);
+                forms_apply(&F, Ut, w2);
+                int ok = 1;
+                for (int f = 0; f < nf; ++f) {
+                    const double a = bu[f] - w2[f], b = bl[f] + w2[f];
+                    if (!(a > 0.0) || !(b > 0.0)) { ok = 0; break; }
+                    phi -= mu * (log(a) + log(b));
+                }
+                /* small slack for round-off as in Ipopt (10 * eps * |phi|) */
+                if (ok && phi - phi0 - 10.0 * 2.2e-16 * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = 1; break; }
+            }
         }
         if (!accepted) { status = err0 <= 100.0 * o->tol ? KMPC_OPTIMAL : KMPC_NUMERICAL_ERROR; break; }  /* acceptable level reached */
         if (getenv("KMPC_TRACE")) fprintf(stderr, "it %3d J %.10g err0 %.3e mu %.2e ap %.3g ad %.3g alpha %.3g rd %.3e comp %.3e gn %d\n", it, J, err0, mu, ap, ad, alpha, rdmax, cmax0, use_gn);
@@ -527,6 +590,7 @@ finish:
         res->iters = iters;
         res->n_refactor = n_refac;
         res->n_ls = n_ls;
+        res->n_solves = n_solves;
         res->cost = kmpc_cost(p, q, U, Xl);
         res->viol = kmpc_max_violation(p, q, U);
         res->kkt = err0;

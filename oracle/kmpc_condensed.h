@@ -34,6 +34,10 @@ typedef struct kmpc_opts {
     double warm_push;    /* weight of the analytic interior point in the blend (0.01) */
     double warm_mu;      /* mu_init used with a warm start */
     int max_ls;          /* back-tracking steps */
+    int mu_strategy;     /* 0 = Ipopt's monotone Fiacco-McCormick default, 1 = Mehrotra predictor-corrector (adaptive),
+                            -1 (default) = by horizon: 1 for N <= 24, 0 for longer horizons */
+    int indef_strategy;  /* indefinite exact Hessian: 0 = Gauss-Newton fallback (held 2 iterations), 1 = Ipopt-style delta_w shift,
+                            -1 (default) = by horizon: 0 for N <= 24, 1 for longer horizons */
 } kmpc_opts;
 
 typedef struct kmpc_result {
@@ -41,6 +45,7 @@ typedef struct kmpc_result {
     int iters;           /* linearisations == Cholesky factorisations attempted */
     int n_refactor;      /* extra factorisations (exact->GN fallback, regularisation) */
     int n_ls;            /* total back-tracking trial points */
+    int n_solves;        /* triangular solve pairs (1 per iteration monotone; 2+ with the predictor) */
     double cost;         /* unscaled objective at the returned U */
     double viol;         /* max inequality violation vs. the unrelaxed bounds */
     double kkt;          /* final scaled optimality error E_0 */

@@ -34,11 +34,11 @@ class Problem(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("tol", C.c_double), ("hessian", C.c_int),
                 ("mu_init", C.c_double), ("bound_relax", C.c_double), ("warm", C.c_int),
-                ("warm_push", C.c_double), ("warm_mu", C.c_double), ("max_ls", C.c_int)]
+                ("warm_push", C.c_double), ("warm_mu", C.c_double), ("max_ls", C.c_int), ("mu_strategy", C.c_int), ("indef_strategy", C.c_int)]
 
 
 class Result(C.Structure):
-    _fields_ = [("status", C.c_int), ("iters", C.c_int), ("n_refactor", C.c_int), ("n_ls", C.c_int),
+    _fields_ = [("status", C.c_int), ("iters", C.c_int), ("n_refactor", C.c_int), ("n_ls", C.c_int), ("n_solves", C.c_int),
                 ("cost", C.c_double), ("viol", C.c_double), ("kkt", C.c_double), ("mu", C.c_double)]
 
 
@@ -178,7 +178,7 @@ def solve_condensed(p, q, o=None, U0=None):
     r = Result()
     lib().kmpc_condensed_solve(C.byref(p), C.byref(q.c), C.byref(o), _p(U), _p(X), _p(lam), C.byref(r))
     return dict(U=U.reshape(N, 2), X=X, lam=lam, status=r.status, iters=r.iters, n_refactor=r.n_refactor,
-                n_ls=r.n_ls, cost=r.cost, viol=r.viol, kkt=r.kkt, mu=r.mu)
+                n_ls=r.n_ls, n_solves=r.n_solves, cost=r.cost, viol=r.viol, kkt=r.kkt, mu=r.mu)
 
 
 def solve_condensed_batch(p, z0, ref, v_target, u_prev, o=None, U0=None, nthreads=1, want_X=False):

@@ -8,12 +8,12 @@ from mkz_mpc_path_follower_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "mkz_mpc_path_follower_amd", "libkmpc_hip_stamps.so")
 from mkz_mpc_path_follower_amd import BatchMPC
 from mkz_mpc_path_follower_amd.synthetic import make_batch
-NAMES = ["setup", "linearize", "residual+mu", "condense", "build_K", "cholesky", "rhs", "chol_solve", "step+ftb", "linesearch", "exit", "outputs"]
+NAMES = ["setup", "linearize", "residual+mu", "condense", "build_K", "chol:backsub", "rhs", "predictor", "step+ftb", "eval+trial", "exit", "outputs", "chol:sweep1", "chol:schur", "chol:sweep2", "corr solve"]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 for B in (1, 4096):
     s = BatchMPC(N=N)
     L = _lib.load()
-    st = torch.zeros((B, 12), dtype=torch.int64, device="cuda")
+    st = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
     L.kmpc_debug_set_stamps.argtypes = [C.c_void_p]
     L.kmpc_debug_set_stamps(C.c_void_p(st.data_ptr()))
     d = make_batch(B, N, cfg_id=2)
@@ -25,3 +25,19 @@ for B in (1, 4096):
     print("B=%d N=%d mean iters %.2f, mean cycles/solve %.0f, cycles/iter %.0f" % (B, N, it.mean(), tot.mean(), (tot / it).mean()))
     for i, nm in enumerate(NAMES):
         print("   %-12s %9.0f cyc/iter  %5.1f %%" % (nm, (c[:, i] / it).mean(), 100 * c[:, i].sum() / tot.sum()))
+
+# ---- tail analysis at the bench batch: which problems determine the launch time --------------------------------
+B = 4096
+s = BatchMPC(N=N)
+st = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
+L.kmpc_debug_set_stamps(C.c_void_p(st.data_ptr()))
+d = make_batch(B, N, cfg_id=2)
+o = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"])
+torch.cuda.synchronize()
+it = o["iters"].cpu().numpy(); c = st.cpu().numpy().astype(np.float64); tot = c.sum(1)
+order = np.argsort(-tot)[:8]
+print("slowest problems of the B=4096 bench batch (wave lifetime in cycles; mean %.0f):" % tot.mean())
+for b in order:
+    nfac = c[b, 12] / max(c[order, 12].min() / 1.0, 1.0)
+    print("  b=%4d iters %3d cycles %.0f (%.1fx mean)  hard=%s  condense share %.0f%%  sweep1 %.0f cyc/iter" % (b, it[b], tot[b], tot[b] / tot.mean(), d["hard"][b], 100 * c[b, 3] / tot[b], c[b, 12] / it[b]))
+print("iters histogram:", np.bincount(it)[:40])
