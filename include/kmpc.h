@@ -73,8 +73,8 @@ typedef struct kmpc_config {
     int32_t mu_strategy;    /* barrier update: 0 = Ipopt's default monotone (Fiacco-McCormick), 1 = Mehrotra predictor-corrector
                                (Ipopt's adaptive family); kmpc_config_default picks 1 for N <= 24, 0 for longer horizons */
     int32_t indef_strategy; /* exact Hessian not positive definite: 0 = Gauss-Newton fallback (held for 2 iterations), 1 = Ipopt-style
-                               delta_w shift of the exact Hessian; kmpc_config_default picks 0 for N <= 24, 1 for longer horizons.
-                               (The compile-time-horizon kernel implements 0; 1 runs on the generic kernel.) */
+                               delta_w shift of the exact Hessian, 2 = hybrid (0 until the second failure of a solve, 1 from then on);
+                               kmpc_config_default picks 2 for N <= 24, 1 for longer horizons */
 } kmpc_config;
 
 typedef struct kmpc_handle kmpc_handle;

@@ -79,7 +79,7 @@ extern "C" int32_t kmpc_config_default(kmpc_config *c, int32_t N, int32_t dtype)
     c->warm_push = 0.01;
     c->warm_mu = 1e-3;
     c->max_ls = 30;
-    c->indef_strategy = N <= 24 ? 0 : 1;  // indefinite exact Hessian: GN fallback for short horizons, delta_w shift for long ones
+    c->indef_strategy = N <= 24 ? 2 : 1;  // indefinite exact Hessian: hybrid (GN fallback, then delta_w shift) for short horizons, shift for long ones
     c->mu_strategy = N <= 24 ? 1 : 0;  // Mehrotra is validated for short horizons; longer ones keep Ipopt's monotone default
     return KMPC_OK;
 }
@@ -93,7 +93,7 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
         !(cfg->v_max > cfg->v_min) || !(cfg->a_max > 0) || !(cfg->steer_max > 0) || !(cfg->steer_max < 1.5) ||
         !(cfg->a_dmax > 0) || !(cfg->steer_dmax > 0) || cfg->max_iter < 1 || cfg->max_ls < 1 || !(cfg->tol > 0) ||
         cfg->kernel_variant < 0 || cfg->kernel_variant > 1 || cfg->mu_strategy < 0 || cfg->mu_strategy > 1 ||
-        cfg->indef_strategy < 0 || cfg->indef_strategy > 1)
+        cfg->indef_strategy < 0 || cfg->indef_strategy > 2)
         return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: invalid model / solver parameter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_create: no HIP device");
@@ -174,7 +174,7 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
     io.iters = iters; io.outU = (T *)outU; io.outX = (T *)outX;
     io.stamps = g_stamps;
     const KP P = make_kp(h, B, warm && warmU ? 1 : 0, -1);
-    if (h->cfg.kernel_variant == 0 && P.indef_strategy == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));
+    if (h->cfg.kernel_variant == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));
     else HIPCHK(h, kmpc_launch_solve<T>(P, io, st));
     return KMPC_OK;
 }

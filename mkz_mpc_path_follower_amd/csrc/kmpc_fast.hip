@@ -630,7 +630,8 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i]); lu[i] = ll[i] = au[i] = aut[i] = (T)0; }
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
-        T err_last = (T)1e30, Ubest = 0;
+        T err_last = (T)1e30, Ubest = 0, rds = 0, dw_last = 0, hmax = 0;
+        int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
         bool have_best = false;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, Jt = 0, alpha = 0, ad = 0, phi0 = 0, dphi = 0, reg = 0;
         bool use_exact = exact;
@@ -676,7 +677,7 @@ template <typename T, int N> struct FastSolver {
                 // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
                 Ut = Ubest; U = Ubest; status = 0;
             }
-            if (mode != REFACTOR) Jt = eval(Ut, St);  // a refactor pass re-uses the evaluation and the stage scalars of U
+            if (mode != REFACTOR && mode != RESTEP) Jt = eval(Ut, St);  // refactor / restep passes re-use the linearisation of U
             STAMP(9);
             if (mode == FINAL) break;
             if (mode == TRIAL) {
@@ -691,8 +692,9 @@ template <typename T, int N> struct FastSolver {
                 okp = __all(okp);
                 const T phi = sc * Jt - mu * dpp_sum(lgt);
                 if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi)) {
+                    // safeguard: the corrected direction is tried at the full step only; redo the step without the corrector term
+                    if (corr_active) { mode = RESTEP; Ut = U; continue; }
                     if (++ls >= P.max_ls) {
-                        if (corr_active) { mode = RESTEP; Ut = U; continue; }  // safeguard: redo the step without the corrector term
                         status = err_last <= (T)100 * tol ? 0 : 3; mode = FINAL; Ut = U; continue;  // acceptable level
                     }
                     alpha *= (T)0.5;
@@ -747,7 +749,7 @@ template <typename T, int N> struct FastSolver {
                 const T s_d = fmax(s_max, lsum / (T)(2 * nf)) / s_max;
                 const T err0 = fmax(rdm, cm0) / s_d;
                 const T gap_lim = gap_tol * fmax((T)1, fabs(J));
-                err_last = err0;
+                err_last = err0; rds = rdm / s_d;
                 // Ipopt's test (+ gap bound, pursued for at most 1 more iteration once Ipopt's test is met), or
                 // Ipopt's "acceptable level" (error <= 100*tol for 15 iterations in a row)
                 bool done = false;
@@ -783,6 +785,15 @@ template <typename T, int N> struct FastSolver {
             {
                 acc_t acc[NTT];
                 condense(use_exact, sc, acc);
+                if (use_exact && indef == 1 && reg == (T)0) {  // max |sc * H_jj| over the diagonal of the tiles: scale of the delta_w shift
+                    T hm = 0;
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[ti * (ti + 1) / 2 + ti][r]));
+                    hmax = dpp_max(hm);
+                }
                 STAMP(3);
                 build_K(acc, sc, reg, rhs);
                 STAMP(4);
@@ -790,12 +801,22 @@ template <typename T, int N> struct FastSolver {
             factored = factor();
             STAMP(5);
             if (!factored) {
-                if (++attempt >= 14) { status = 3; mode = FINAL; Ut = U; continue; }
-                if (use_exact) { use_exact = false; gn_hold = 2; mode = REFACTOR; Ut = U; continue; }  // drop the second-order term first
-                reg = reg == 0 ? (T)1e-8 : reg * (T)100;                                   // then delta_w escalation
+                // Indefinite exact Hessian: strategy 0 -> Gauss-Newton for this and the next 2 iterations; 1 -> Ipopt's inertia
+                // correction K + delta_w*I, delta_w = 1e-4*max|sc*H_jj| (x100) the first time, last/3 (x8) afterwards;
+                // 2 -> 0 until the second failure, 1 from then on (Gauss-Newton leaves a saddle only slowly)
+                if (++attempt >= 40) { status = 3; mode = FINAL; Ut = U; continue; }
+                if (use_exact && indef == 1) {
+                    if (reg == (T)0) reg = dw_last > (T)0 ? fmax((T)1e-10 * hmax, dw_last / (T)3) : (T)1e-4 * hmax;
+                    else reg *= dw_last > (T)0 ? (T)8 : (T)100;
+                    if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; }
+                } else if (use_exact) {
+                    use_exact = false; gn_hold = 2;
+                    if (P.indef_strategy == 2 && ++n_fail >= 2) { indef = 1; gn_hold = 0; }
+                } else reg = reg == (T)0 ? (T)1e-8 : reg * (T)100;  // last resort: shift the Gauss-Newton matrix
                 mode = REFACTOR; Ut = U;
                 continue;
             }
+            if (use_exact && reg > (T)0) dw_last = reg;
             ya = lane < n ? Lc[offc_rt(lane) + n] : (T)0;  // L^{-1}(-sc*g)
 #pragma unroll
             for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
@@ -828,6 +849,7 @@ template <typename T, int N> struct FastSolver {
                 mucur = dpp_sum(mucur) / (T)(2 * nf); muaff = dpp_sum(muaff) / (T)(2 * nf);
                 const T r3 = muaff / mucur;
                 mu = fmax(mu_floor, fmin((T)1, r3 * r3 * r3) * mucur);
+                mu = fmax(mu, fmin(mucur, rds / (T)1e3));  // no barrier target far below the dual infeasibility
                 corr_active = true;
                 STAMP(7);
             }

@@ -459,6 +459,7 @@ template <typename T, int NT> struct Solver {
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i], rlx[i]); }
         int status = 1, iters = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
         T dw_last = 0;
+        int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
         bool have_best = false;
         T Ubest[NV];
 #pragma unroll
@@ -578,7 +579,7 @@ template <typename T, int NT> struct Solver {
                     if (need_condense) {
                         condense(use_exact, acc);
                         need_condense = false;
-                        if (P.indef_strategy == 1 && use_exact) {  // max |sc * H_jj| over the diagonal of the tiles
+                        if (indef == 1 && use_exact) {  // max |sc * H_jj| over the diagonal of the tiles
                             T hm = 0;
 #pragma unroll
                             for (int ti = 0; ti < NT; ++ti)
@@ -595,11 +596,14 @@ template <typename T, int NT> struct Solver {
                     const bool okc = cholesky();
                     STAMP(5);
                     if (okc) { factored = true; if (use_exact && reg > 0) dw_last = reg; break; }
-                    if (use_exact && P.indef_strategy == 1) {
+                    if (use_exact && indef == 1) {
                         if (reg == 0) reg = dw_last > 0 ? fmax((T)1e-10 * hmax, dw_last / 3) : (T)1e-4 * hmax;
                         else reg *= dw_last > 0 ? (T)8 : (T)100;
                         if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; need_condense = true; }
-                    } else if (use_exact) { use_exact = false; gn_hold = 2; need_condense = true; }  // drop the second-order term
+                    } else if (use_exact) {  // drop the second-order term
+                        use_exact = false; gn_hold = 2; need_condense = true;
+                        if (P.indef_strategy == 2 && ++n_fail >= 2) { indef = 1; gn_hold = 0; }
+                    }
                     else reg = reg == 0 ? (T)1e-8 : reg * (T)100;  // last resort: shift the Gauss-Newton matrix
                 }
                 if (!factored) { status = 3; break; }
@@ -637,6 +641,7 @@ template <typename T, int NT> struct Solver {
                     mucur = wave_sum(mucur) / (T)(2 * nf); muaff = wave_sum(muaff) / (T)(2 * nf);
                     const T r3 = muaff / mucur;
                     mu = fmax(mu_min, fmin((T)1, r3 * r3 * r3) * mucur);
+                    mu = fmax(mu, fmin(mucur, rdm / s_d / (T)1e3));  // no barrier target far below the dual infeasibility
                 }
                 const T tau = fmax(tau_min, (T)1 - mu);
                 T ad = 1, Jt = 0;
@@ -684,7 +689,8 @@ template <typename T, int NT> struct Solver {
                     dphi = wave_sum(dphi);
                     STAMP(8);
                     T alpha = ap;
-                    for (int l = 0; l < P.max_ls; ++l, alpha *= (T)0.5) {
+                    const int nls = (pass == 0 && P.mu_strategy == 1) ? 1 : P.max_ls;  // the corrected direction is tried at the full step only
+                    for (int l = 0; l < nls; ++l, alpha *= (T)0.5) {
 #pragma unroll
                         for (int i = 0; i < NV; ++i) Ut[i] = U[i] + alpha * du[i];
                         Jt = eval(Ut, St);
