@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KMPC_ABI_VERSION 2
+#define KMPC_ABI_VERSION 3
 
 /* per-problem status, replaces the Symbol returned by solve_model() (MKZMPCPathFollower.jl:176,182) */
 enum {
@@ -75,6 +75,10 @@ typedef struct kmpc_config {
     int32_t indef_strategy; /* exact Hessian not positive definite: 0 = Gauss-Newton fallback (held for 2 iterations), 1 = Ipopt-style
                                delta_w shift of the exact Hessian, 2 = hybrid (0 until the second failure of a solve, 1 from then on);
                                kmpc_config_default picks 2 for N <= 24, 1 for longer horizons */
+    int32_t schedule;       /* order in which the problems of a batch start on the GPU: 0 = index order, 1 (default) = longest
+                               predicted first (key = |v0 - reference speed| + 1.33 * total heading change of the reference), which
+                               shortens the tail of a launch whose time is set by its slowest problems.  Results do not depend on it.
+                               Calls on one handle must be stream-ordered (the permutation workspace belongs to the handle). */
 } kmpc_config;
 
 typedef struct kmpc_handle kmpc_handle;

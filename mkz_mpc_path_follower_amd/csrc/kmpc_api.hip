@@ -17,6 +17,7 @@ template <typename T> hipError_t kmpc_launch_condense(const KP &, const KDbg<T> 
 template <typename T> hipError_t kmpc_launch_probe(const T *, const T *, T *, hipStream_t);
 template <typename T> bool kmpc_fast_available(int N);
 template <typename T> hipError_t kmpc_launch_solve_fast(const KP &, const KIO<T> &, hipStream_t);
+template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, const T *, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
 
 struct kmpc_handle {
     kmpc_config cfg;
@@ -27,6 +28,11 @@ struct kmpc_handle {
     // staging for the host-pointer entry point
     void *dbuf;
     size_t dbuf_bytes;
+    // start-order workspace (kmpc_schedule.hip): perm[cap], tag[cap], hist[2][256]
+    int32_t *perm;
+    uint32_t *tag, *hist;
+    size_t sched_cap;
+    unsigned sched_parity;
 };
 
 static std::string g_create_err;
@@ -80,6 +86,7 @@ extern "C" int32_t kmpc_config_default(kmpc_config *c, int32_t N, int32_t dtype)
     c->warm_mu = 1e-3;
     c->max_ls = 30;
     c->indef_strategy = N <= 24 ? 2 : 1;  // indefinite exact Hessian: hybrid (GN fallback, then delta_w shift) for short horizons, shift for long ones
+    c->schedule = 1;  // longest-predicted-first start order (kmpc_schedule.hip)
     c->mu_strategy = N <= 24 ? 1 : 0;  // Mehrotra is validated for short horizons; longer ones keep Ipopt's monotone default
     return KMPC_OK;
 }
@@ -93,7 +100,7 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
         !(cfg->v_max > cfg->v_min) || !(cfg->a_max > 0) || !(cfg->steer_max > 0) || !(cfg->steer_max < 1.5) ||
         !(cfg->a_dmax > 0) || !(cfg->steer_dmax > 0) || cfg->max_iter < 1 || cfg->max_ls < 1 || !(cfg->tol > 0) ||
         cfg->kernel_variant < 0 || cfg->kernel_variant > 1 || cfg->mu_strategy < 0 || cfg->mu_strategy > 1 ||
-        cfg->indef_strategy < 0 || cfg->indef_strategy > 2)
+        cfg->indef_strategy < 0 || cfg->indef_strategy > 2 || cfg->schedule < 0 || cfg->schedule > 1)
         return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: invalid model / solver parameter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_create: no HIP device");
@@ -107,6 +114,7 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
     h->device = device;
     h->dbuf = nullptr;
     h->dbuf_bytes = 0;
+    h->perm = nullptr; h->tag = nullptr; h->hist = nullptr; h->sched_cap = 0; h->sched_parity = 0;
     const double w0[8] = {9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0};  // :51-59
     memcpy(h->cost, w0, sizeof w0);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -123,6 +131,9 @@ extern "C" int32_t kmpc_destroy(kmpc_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->dbuf) (void)hipFree(h->dbuf);
+    if (h->perm) (void)hipFree(h->perm);
+    if (h->tag) (void)hipFree(h->tag);
+    if (h->hist) (void)hipFree(h->hist);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return KMPC_OK;
@@ -174,6 +185,28 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
     io.iters = iters; io.outU = (T *)outU; io.outX = (T *)outX;
     io.stamps = g_stamps;
     const KP P = make_kp(h, B, warm && warmU ? 1 : 0, -1);
+    io.perm = nullptr;
+    // start order: only matters once a launch no longer fits on the chip at once (2 waves x 4 SIMDs x 256 CUs)
+    if (h->cfg.schedule == 1 && B > 2048) {
+        if ((size_t)B > h->sched_cap) {
+            if (h->perm) (void)hipFree(h->perm);
+            if (h->tag) (void)hipFree(h->tag);
+            h->perm = nullptr; h->tag = nullptr; h->sched_cap = 0;
+            const size_t cap = (size_t)B + (size_t)B / 4;
+            HIPCHK(h, hipMalloc((void **)&h->perm, cap * sizeof(int32_t)));
+            HIPCHK(h, hipMalloc((void **)&h->tag, cap * sizeof(uint32_t)));
+            h->sched_cap = cap;
+        }
+        if (!h->hist) {
+            HIPCHK(h, hipMalloc((void **)&h->hist, 2 * 256 * sizeof(uint32_t)));
+            HIPCHK(h, hipMemsetAsync(h->hist, 0, 2 * 256 * sizeof(uint32_t), st));
+            h->sched_parity = 0;
+        }
+        uint32_t *hc = h->hist + 256 * (h->sched_parity & 1), *hn = h->hist + 256 * ((h->sched_parity & 1) ^ 1);
+        HIPCHK(h, kmpc_launch_schedule<T>(B, P.N, P.dt, io.z0, io.ref, hc, hn, h->tag, h->perm, st));
+        h->sched_parity ^= 1;
+        io.perm = h->perm;
+    }
     if (h->cfg.kernel_variant == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));
     else HIPCHK(h, kmpc_launch_solve<T>(P, io, st));
     return KMPC_OK;

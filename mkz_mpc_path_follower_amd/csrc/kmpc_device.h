@@ -23,6 +23,7 @@ struct KIO {
     int32_t *iters;
     T *outU, *outX;
     unsigned long long *stamps;  // diagnostic builds only (KMPC_STAMPS), else NULL
+    const int32_t *perm;         // start order: workgroup i solves problem perm[i] (NULL = index order)
 };
 
 template <typename T>

@@ -327,65 +327,74 @@ template <typename T, int N> struct FastSolver {
     // The remaining second-order rows -- row rho = 2s+1 (d_f of stage s): mpd*G_psi + mvd*G_v, mdd on the diagonal -- are
     // written, scaled by sc, straight into the packed K image by the lane of each column; they define every ODD row of
     // the image (build_K then adds to odd rows, stores even rows).
+    struct Rec { T a02, a03, a12, a13, a23, bx, by, bp, mpp, mpv, mpd, mvd, mdd; };
+    DEV void load_rec(Rec &r, int s, T exs) const
+    {
+        const T *q = lin + LIN_STRIDE * s;  // record N is all zero (linearize)
+        r.a02 = q[0]; r.a03 = q[1]; r.a12 = q[2]; r.a13 = q[3]; r.a23 = q[4]; r.bx = q[5]; r.by = q[6]; r.bp = q[7];
+        r.mpp = exs * q[8]; r.mpv = exs * q[9]; r.mpd = exs * q[10]; r.mvd = exs * q[11]; r.mdd = exs * q[12];
+    }
     DEV void condense(bool exact, T sc, acc_t (&acc)[NTT])
     {
         const int kk = lane >> 4, c = lane & 15;
 #pragma unroll
         for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
-        T gx = 0, gy = 0, gp = 0, gv = 0;            // column `lane` of G at the current stage
+        T gx = 0, gy = 0, gp = 0, gv = 0;            // column `lane` of G at the current state
         const T pef = (lane & 1) ? (T)1 : (T)0;      // d_f columns take B's steering column, acc columns (0,0,0,dt)
         const T gvnew = (lane & 1) ? (T)0 : dt;
         T *colK = Lc + offc_rt(lane < n ? lane : 0);  // column `lane` of the packed K image
         const T exs = exact ? (T)1 : (T)0;
-        T fa[NT], fb[NT];                            // MFMA fragments of the stage in flight
+        T fa[NT], fb[NT];                            // MFMA fragments of the state whose products are still to be issued
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fa[t] = fb[t] = (T)0;
+        // stage records are fetched one trip ahead: no LDS round trip on the recursion's path
+        Rec cur;
+        load_rec(cur, 0, exs);
 #pragma nounroll
-        for (int s = 0; s <= N; ++s) {
-            // ---- stage s record: second-order scalars of stage s; transition s -> s+1 ------------------------------
-            const T *q = lin + LIN_STRIDE * (s < N ? s : N - 1);
-            const T ex_ = s < N ? exs : (T)0;
-            const T mpp = ex_ * q[8], mpv = ex_ * q[9], mpd = ex_ * q[10], mvd = ex_ * q[11], mdd = ex_ * q[12];
-            if (s >= 1) {
-                // fragments of state s were issued at the end of the previous trip; feed the matrix cores
+        for (int s = 0; s < N; ++s) {
+            Rec nxt;
+            load_rec(nxt, s + 1, exs);
+            // odd row rho = 2s+1 of the image from G_s (zero second-order part when !exact)
+            const int rho = 2 * s + 1;
+            const T val = sc * (cur.mpd * gp + cur.mvd * gv) + (lane == rho ? sc * cur.mdd : (T)0);
+            T *dst = (lane <= rho && lane < n) ? colK + rho : xb + lane;
+            *dst = val;
+            // ---- advance the recursion to state s+1 ---------------------------------------------------------------
+            gx += cur.a02 * gp + cur.a03 * gv;
+            gy += cur.a12 * gp + cur.a13 * gv;
+            gp += cur.a23 * gv;
+            const bool isnew = (lane >> 1) == s;   // columns 2s, 2s+1 enter with B_s
+            gx = isnew ? cur.bx * pef : gx;
+            gy = isnew ? cur.by * pef : gy;
+            gp = isnew ? cur.bp * pef : gp;
+            gv = isnew ? gvnew : gv;
+            // weights of state s+1: 2Q_{s+1} + M_{s+1}^{psi,v}
+            const T Cv1 = s + 1 <= N - 1 ? (T)2 * Cv : (T)0;
+            // component-major staging: opb[comp][col]
+            opb[0 * 64 + lane] = gx; opb[1 * 64 + lane] = gy; opb[2 * 64 + lane] = gp; opb[3 * 64 + lane] = gv;
+            opb[4 * 64 + lane] = (T)2 * Cx * gx;
+            opb[5 * 64 + lane] = (T)2 * Cy * gy;
+            opb[6 * 64 + lane] = ((T)2 * Cp + nxt.mpp) * gp + nxt.mpv * gv;
+            opb[7 * 64 + lane] = Cv1 * gv + nxt.mpv * gp;
+            WFENCE();
+            // products of state s (fragments fetched one trip ago) go to the matrix cores; then the same registers take the
+            // fragments of state s+1, whose LDS latency is covered by the next trip's recursion work
 #pragma unroll
-                for (int ti = 0; ti < NT; ++ti)
-                    if (16 * ti < 2 * s) {
+            for (int ti = 0; ti < NT; ++ti)
+                if (16 * ti < 2 * s) {
 #pragma unroll
-                        for (int tj = 0; tj <= ti; ++tj)
-                            acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc[ti * (ti + 1) / 2 + tj]);
-                    }
-            }
-            if (s < N) {
-                // odd row rho = 2s+1 of the image from G_s (zero second-order part when !exact)
-                const int rho = 2 * s + 1;
-                const T val = sc * (mpd * gp + mvd * gv) + (lane == rho ? sc * mdd : (T)0);
-                T *dst = (lane <= rho && lane < n) ? colK + rho : xb + lane;
-                *dst = val;
-                // ---- advance the recursion to state s+1 -----------------------------------------------------------
-                const T A02 = q[0], A03 = q[1], A12 = q[2], A13 = q[3], A23 = q[4], Bdx = q[5], Bdy = q[6], Bdp = q[7];
-                gx += A02 * gp + A03 * gv;
-                gy += A12 * gp + A13 * gv;
-                gp += A23 * gv;
-                const bool isnew = (lane >> 1) == s;   // columns 2s, 2s+1 enter with B_s
-                gx = isnew ? Bdx * pef : gx;
-                gy = isnew ? Bdy * pef : gy;
-                gp = isnew ? Bdp * pef : gp;
-                gv = isnew ? gvnew : gv;
-                // weights of state s+1: 2Q_{s+1} + M_{s+1}^{psi,v}  (needs stage s+1's second-order scalars)
-                const T *q1 = lin + LIN_STRIDE * (s + 1 < N ? s + 1 : N - 1);
-                const T ex1 = s + 1 < N ? exs : (T)0;
-                const T mpp1 = ex1 * q1[8], mpv1 = ex1 * q1[9];
-                const T Cv1 = s + 1 <= N - 1 ? (T)2 * Cv : (T)0;
-                // component-major staging: opb[comp][col]
-                opb[0 * 64 + lane] = gx; opb[1 * 64 + lane] = gy; opb[2 * 64 + lane] = gp; opb[3 * 64 + lane] = gv;
-                opb[4 * 64 + lane] = (T)2 * Cx * gx;
-                opb[5 * 64 + lane] = (T)2 * Cy * gy;
-                opb[6 * 64 + lane] = ((T)2 * Cp + mpp1) * gp + mpv1 * gv;
-                opb[7 * 64 + lane] = Cv1 * gv + mpv1 * gp;
-                WFENCE();
+                    for (int tj = 0; tj <= ti; ++tj)
+                        acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc[ti * (ti + 1) / 2 + tj]);
+                }
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { fa[t] = opb[kk * 64 + 16 * t + c]; fb[t] = opb[(4 + kk) * 64 + 16 * t + c]; }
-            }
+            for (int t = 0; t < NT; ++t) { fa[t] = opb[kk * 64 + 16 * t + c]; fb[t] = opb[(4 + kk) * 64 + 16 * t + c]; }
+            cur = nxt;
         }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj)
+                acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc[ti * (ti + 1) / 2 + tj]);
     }
 
     // packed KKT image: lower triangle of sc*(H + input Hessian) + A^T W A + reg*I, and the rhs as row n.
@@ -435,111 +444,106 @@ template <typename T, int N> struct FastSolver {
         WSYNC();
     }
 
-    // One rolled elimination sweep over columns [j0, j1): lane i holds the live part of row i in
-    // slot[] with the CURRENT pivot column at slot[0] (the array shifts one place per step, so all
-    // register indices are static).  LEN = number of trailing entries that still matter.
-    // `l` enters holding column j0 of L (pivot already taken), and leaves holding column j1 (if any).
-    template <int LEN> DEV void chol_sweep(T (&slot)[N], int j0, int j1, T &l, bool &ok)
+    // ---- blocked Cholesky on the matrix cores -----------------------------------------------------------------
+    // K (with the rhs as row n) is held in MFMA C-layout tiles kt[] (lower 16x16 tiles, diagonal tiles symmetric).
+    // One block-step takes a 4-column panel j0..j0+3:
+    //   1. the lanes holding those columns put them into the LDS scratch pan[row][4];
+    //   2. every lane reads the 4x4 diagonal block (uniform addresses) and factors it redundantly (4 rsqrt chains);
+    //   3. lane (kk = lane>>4, c = lane&15) solves the panel rows 16t + c against it -- x L_dd^T = a, 10 FMAs -- keeps
+    //      component kk: exactly the A/B fragment layout of the 16x16x4 MFMA -- and stores it as column j0+kk of L;
+    //   4. trailing tiles -= P P^T, one MFMA per live tile.
+    // 2N/4 block-steps of ~170 instructions replace 2N rank-1 column steps; dead rows are zeroed in the fragments,
+    // so finished entries are never touched again.
+    static constexpr int NTF = (n + 1 + 15) / 16, NTTF = NTF * (NTF + 1) / 2;
+    template <int TJ> DEV bool chol_blocks(acc_t (&kt)[NTTF], int jb0, int jb1)
     {
+        const int c = lane & 15, kk = lane >> 4;
+        T *pan = opb;
 #pragma nounroll
-        for (int j = j0; j < j1; ++j) {
-            const int oc = offc_rt(j);
-            T *dst = (lane >= j && lane <= n) ? Lc + oc + lane : xb + lane;  // branch-free: others hit a dummy word
-            *dst = l;                     // column j of L: broadcast source now, Schur / back-substitution input later
+        for (int jb = jb0; jb < jb1; ++jb) {
+            const int j0 = 4 * jb, kp = c - (j0 & 15);
+            const bool holder = kp >= 0 && kp < 4;
+#pragma unroll
+            for (int ti = TJ; ti < NTF; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + Real<T>::row_of(lane, r);
+                    T *dst = holder ? pan + 4 * row + kp : xb + lane;
+                    *dst = kt[ti * (ti + 1) / 2 + TJ][r];
+                }
             WFENCE();
-            // multipliers L[j+2+p][j] of the trailing entries: uniform-address LDS reads, all issued up front
-            const T *pb = Lc + oc + j + 2;
-            T m[LEN > 1 ? LEN - 1 : 1];
+            const T *pd = pan + 4 * j0;
+            const T d00 = pd[0], d10 = pd[4], d11 = pd[5], d20 = pd[8], d21 = pd[9], d22 = pd[10];
+            const T d30 = pd[12], d31 = pd[13], d32 = pd[14], d33 = pd[15];
+            // panel rows are independent of the diagonal factor until the solve: issue their loads now
+            T a[NTF][4];
 #pragma unroll
-            for (int p = 0; p + 1 < LEN; ++p) m[p] = pb[p];
-            // look-ahead: the NEXT pivot entry needs only registers -- its multiplier L[j+1][j] is lane j+1's own l --
-            // so the next column's rsqrt chain runs while the LDS broadcast above is still in flight
-            const T s0 = fma(-l, readlane_(l, j + 1 < 64 ? j + 1 : 63), slot[1]);
-            const T dn = readlane_(s0, j + 1 < 64 ? j + 1 : 63);
-            const T lnext = s0 * rsqrt_(dn);
-            if (j + 1 < j1 || j1 == 0) ok = ok && (dn > Real<T>::tiny()) && (dn < (T)1e300);
+            for (int t = TJ; t < NTF; ++t)
 #pragma unroll
-            for (int p = 1; p < LEN; ++p) slot[p] = fma(-l, m[p - 1], slot[p + 1 < N ? p + 1 : N - 1]);
-            slot[0] = s0;
-            l = lnext;
-            if (!ok) return;  // indefinite: stop at the first bad pivot (wave-uniform)
+                for (int k = 0; k < 4; ++k) a[t][k] = pan[4 * (16 * t + c) + k];
+            const T r0 = rsqrt_(d00);
+            const T l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+            const T e11 = fma(-l10, l10, d11), r1 = rsqrt_(e11);
+            const T l21 = fma(-l20, l10, d21) * r1, l31 = fma(-l30, l10, d31) * r1;
+            const T e22 = fma(-l21, l21, fma(-l20, l20, d22)), r2 = rsqrt_(e22);
+            const T l32 = fma(-l31, l21, fma(-l30, l20, d32)) * r2;
+            const T e33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33))), r3 = rsqrt_(e33);
+            const T dmin = fmin(fmin(d00, e11), fmin(e22, e33)), dmax = fmax(fmax(d00, e11), fmax(e22, e33));
+            if (!(dmin > Real<T>::tiny() && dmax < (T)1e300)) return false;  // not positive definite (wave-uniform)
+            T pf[NTF];
+            const int jc = j0 + kk;
+            T *colL = Lc + offc_rt(jc < n ? jc : 0);
+#pragma unroll
+            for (int t = TJ; t < NTF; ++t) {
+                const int row = 16 * t + c;
+                const T x0 = a[t][0] * r0;
+                const T x1 = fma(-x0, l10, a[t][1]) * r1;
+                const T x2 = fma(-x1, l21, fma(-x0, l20, a[t][2])) * r2;
+                const T x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, a[t][3]))) * r3;
+                const T xs = kk == 0 ? x0 : (kk == 1 ? x1 : (kk == 2 ? x2 : x3));
+                const bool live = row >= jc && row <= n;
+                pf[t] = live ? xs : (T)0;
+                T *dst = live ? colL + row : xb + lane;
+                *dst = pf[t];
+            }
+            if (j0 + 4 < n) {
+                const int tmin = (j0 + 4) >> 4;  // first tile column that still has live entries
+#pragma unroll
+                for (int tjj = TJ; tjj < NTF; ++tjj)
+                    if (tjj >= tmin) {
+                        const T nb = -pf[tjj];
+#pragma unroll
+                        for (int ti = tjj; ti < NTF; ++ti)
+                            kt[ti * (ti + 1) / 2 + tjj] = Real<T>::mfma(pf[ti], nb, kt[ti * (ti + 1) / 2 + tjj]);
+                    }
+            }
         }
+        return true;
     }
 
-    // In-register Cholesky of the packed image (row n carries a right-hand side, so L^{-1} rhs falls out).
-    // Rows (and the rhs as row n) live one per lane.  Three rolled phases with h = N:
-    //   1. columns 0..h-1      : every row holds its entries of columns 0..h-1
-    //   2. Schur update        : rows h..n load their columns h..n-1 and subtract L21 L21^T
-    //   3. columns h..n-1      : same sweep as phase 1
-    // Column j of L is stored into its packed LDS slot as soon as it is final; the substitution
-    // L^{-1} rhs falls out as row n.
     DEV bool factor()
     {
-        constexpr int h = N;
-        static_assert(N % 4 == 0 && N >= 8, "rolled Cholesky assumes N % 4 == 0");
-        constexpr int L1 = h - 1, L2 = h / 2 - 1;
-        T slot[h];
-        bool ok = true;
+        static_assert(n % 16 == 0 || n % 16 == 8, "block-steps are split at 16-column tile boundaries");
+        const int c = lane & 15;
+        acc_t kt[NTTF];
 #pragma unroll
-        for (int e = 0; e < h; ++e) slot[e] = Lc[offc(e) + lane];
-        T lcol;
-        {
-            const T d0 = readlane_(slot[0], 0);
-            ok = ok && (d0 > Real<T>::tiny()) && (d0 < (T)1e300);
-            lcol = slot[0] * rsqrt_(d0);
-        }
-        chol_sweep<L1>(slot, 0, h / 2, lcol, ok);
-        if (ok) chol_sweep<L2>(slot, h / 2, h, lcol, ok);
-        if (!ok) return false;
+        for (int ti = 0; ti < NTF; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + Real<T>::row_of(lane, r), col = 16 * tj + c;
+                    const int rr = row > col ? row : col, cc = row > col ? col : row;  // diagonal tiles are loaded symmetric
+                    const bool valid = rr <= n && cc < n;
+                    const T v = Lc[valid ? offc_rt(cc) + rr : 0];
+                    kt[ti * (ti + 1) / 2 + tj][r] = valid ? v : (T)0;
+                }
+        WFENCE();
+        bool ok = chol_blocks<0>(kt, 0, (n < 16 ? n : 16) / 4);
         STAMP(12);
-        WFENCE();
-        // ---- phase 2: trailing block (rows h..n incl. the rhs row, columns h..n-1) -= L21 L21^T on the
-        // matrix cores.  L21[i][j] (i >= h, j < h) sits in the packed LDS columns; for the 16x16x4 MFMA both
-        // operands of tile (tr, tc) are "row block of L21, 4 columns": lane (i = l&15, k = l>>4) reads
-        // L21[h + 16*t + i][4*kc + k], so the A fragment of tile-row t is also the B fragment of tile-col t.
-        {
-            constexpr int TR = (n + 1 - h + 15) / 16;  // 16-row blocks of the trailing rows (2 at N = 20)
-            constexpr int KC = h / 4;
-            acc_t sacc[TR * (TR + 1) / 2];
-#pragma unroll
-            for (int t = 0; t < TR * (TR + 1) / 2; ++t) sacc[t] = acc_t{0, 0, 0, 0};
-            const int fi = lane & 15, fk = lane >> 4;
-#pragma nounroll
-            for (int kc = 0; kc < KC; ++kc) {
-                const T *pcol = Lc + offc_rt(4 * kc + fk) + h + fi;
-                T frag[TR];
-#pragma unroll
-                for (int t = 0; t < TR; ++t) frag[t] = pcol[16 * t];
-#pragma unroll
-                for (int tr = 0; tr < TR; ++tr)
-#pragma unroll
-                    for (int tc = 0; tc <= tr; ++tc)
-                        sacc[tr * (tr + 1) / 2 + tc] = Real<T>::mfma(frag[tr], frag[tc], sacc[tr * (tr + 1) / 2 + tc]);
-            }
-            const int c = lane & 15;
-#pragma unroll
-            for (int tr = 0; tr < TR; ++tr)
-#pragma unroll
-                for (int tc = 0; tc <= tr; ++tc)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = h + 16 * tr + Real<T>::row_of(lane, r), col = h + 16 * tc + c;
-                        const bool okw = row <= n && col < n && col <= row;
-                        T *dst = okw ? Lc + offc_rt(okw ? col : 0) + row : xb + lane;
-                        *dst -= sacc[tr * (tr + 1) / 2 + tc][r];
-                    }
-        }
-        WFENCE();
+        if (NTF > 1 && n > 16) { if (ok) ok = chol_blocks<(NTF > 1 ? 1 : 0)>(kt, 4, (n < 32 ? n : 32) / 4); }
         STAMP(13);
-#pragma unroll
-        for (int e = 0; e < h; ++e) slot[e] = Lc[offc(h + e) + lane];
-        {
-            const T d0 = readlane_(slot[0], h);
-            ok = ok && (d0 > Real<T>::tiny()) && (d0 < (T)1e300);
-            lcol = slot[0] * rsqrt_(d0);
-        }
-        chol_sweep<L1>(slot, h, h + h / 2, lcol, ok);
-        chol_sweep<L2>(slot, h + h / 2, n, lcol, ok);
+        if (NTF > 2 && n > 32) { if (ok) ok = chol_blocks<(NTF > 2 ? 2 : 0)>(kt, 8, n / 4); }
         STAMP(14);
         if (!ok) return false;
         WFENCE();
@@ -549,6 +553,8 @@ template <typename T, int N> struct FastSolver {
 
     // Triangular substitutions on the packed factor (lane j <-> component j).  Columns are pre-scaled by the
     // owner's 1/L_jj off the critical path, so the dependent chain per step is just v_readlane + FMA.
+    // (A variant blocked by the 4-column panels -- inverse diagonal blocks, 4 readlanes + 14 FMAs per block -- measured
+    // slower: 600 cycles per block against 4 x 105 for these steps.)
     DEV T fwd_subst(T b)  // solves L y = b
     {
         T wv = b * dinv_l;
@@ -926,8 +932,8 @@ template <typename T, int N>
 __global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : 3) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N>::lds_elems() * sizeof(T)];
-    const int b = blockIdx.x;
-    if (b >= P.B) return;
+    if ((int)blockIdx.x >= P.B) return;
+    const int b = io.perm ? io.perm[blockIdx.x] : (int)blockIdx.x;
     FastSolver<T, N> sv(P, smem);
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
     sv.solve(io, b);

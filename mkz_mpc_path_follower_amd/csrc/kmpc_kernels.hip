@@ -775,8 +775,8 @@ template <typename T, int NT>
 __global__ __launch_bounds__(64) void kmpc_solve_kernel(KP P, KIO<T> io)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
-    if (b >= P.B) return;
+    if ((int)blockIdx.x >= P.B) return;
+    const int b = io.perm ? io.perm[blockIdx.x] : (int)blockIdx.x;
     Solver<T, NT> sv(P, smem);
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
     sv.solve(io, b);

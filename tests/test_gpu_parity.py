@@ -107,6 +107,19 @@ def test_full_size_batch_properties():
     assert np.allclose(X[:, 1:, 3], X[:, :-1, 3] + 0.2 * U[:, :, 0], atol=1e-12)
 
 
+def test_start_order_does_not_change_results():
+    """Longest-predicted-first scheduling (kmpc_config.schedule, kmpc_schedule.hip) only permutes which workgroup
+    solves which problem: every output of every problem is bit-identical to the index-order launch, for both kernels."""
+    N, B = 20, 5000
+    d = make_batch(B, N, cfg_id=4)
+    for variant in (0, 1):
+        a = _solve(N, d, schedule=0, kernel_variant=variant)
+        b = _solve(N, d, schedule=1, kernel_variant=variant)
+        for k in ("status", "iters", "cost", "viol", "u0", "U", "X"):
+            assert np.array_equal(a[k], b[k]), (variant, k)
+        assert (a["status"] == 0).all()
+
+
 def test_infeasible_and_edge_inputs():
     """Q5: v0 outside [0, 20] -> status Infeasible, outputs finite and inside the input box."""
     N = 8
