@@ -636,7 +636,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i]); lu[i] = ll[i] = au[i] = aut[i] = (T)0; }
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
-        T err_last = (T)1e30, Ubest = 0, rds = 0, dw_last = 0, hmax = 0;
+        T err_last = (T)1e30, Ubest = 0, rds = 0, dw_last = 0, dw_spec = 0, hmax = 0;
         int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
         bool have_best = false;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, Jt = 0, alpha = 0, ad = 0, phi0 = 0, dphi = 0, reg = 0;
@@ -644,7 +644,7 @@ template <typename T, int N> struct FastSolver {
         enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3, RESTEP = 4 };
         const bool pc = P.mu_strategy == 1;
         T corru[NF], corrl[NF], ya = 0, mu_floor = 0;
-        bool corr_active = false;
+        bool corr_active = false, first_attempt = true;
 #pragma unroll
         for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
         int mode = FIRST;
@@ -779,6 +779,9 @@ template <typename T, int N> struct FastSolver {
                 }
                 use_exact = exact && gn_hold == 0; reg = 0; attempt = 0;  // GN is held for 2 iterations after an indefinite exact Hessian
                 if (gn_hold > 0) --gn_hold;
+                // in shift mode the previous iteration's delta_w / 3 is the first trial (dropped below 1e-9 * max|H_jj|)
+                if (use_exact && indef == 1 && dw_spec > (T)0) { reg = dw_spec / (T)3; if (reg < (T)1e-9 * hmax) reg = 0; }
+                first_attempt = true;
                 STAMP(2);
             }
             // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
@@ -791,7 +794,7 @@ template <typename T, int N> struct FastSolver {
             {
                 acc_t acc[NTT];
                 condense(use_exact, sc, acc);
-                if (use_exact && indef == 1 && reg == (T)0) {  // max |sc * H_jj| over the diagonal of the tiles: scale of the delta_w shift
+                if (use_exact && indef == 1 && first_attempt) {  // max |sc * H_jj| over the diagonal of the tiles: scale of the delta_w shift
                     T hm = 0;
 #pragma unroll
                     for (int ti = 0; ti < NT; ++ti)
@@ -800,6 +803,7 @@ template <typename T, int N> struct FastSolver {
                             if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[ti * (ti + 1) / 2 + ti][r]));
                     hmax = dpp_max(hm);
                 }
+                first_attempt = false;
                 STAMP(3);
                 build_K(acc, sc, reg, rhs);
                 STAMP(4);
@@ -823,6 +827,7 @@ template <typename T, int N> struct FastSolver {
                 continue;
             }
             if (use_exact && reg > (T)0) dw_last = reg;
+            if (use_exact) dw_spec = reg;
             ya = lane < n ? Lc[offc_rt(lane) + n] : (T)0;  // L^{-1}(-sc*g)
 #pragma unroll
             for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;

@@ -458,7 +458,7 @@ template <typename T, int NT> struct Solver {
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i], rlx[i]); }
         int status = 1, iters = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
-        T dw_last = 0;
+        T dw_last = 0, dw_spec = 0, hmax = 0;
         int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
         bool have_best = false;
         T Ubest[NV];
@@ -573,7 +573,9 @@ template <typename T, int NT> struct Solver {
                 // Indefinite exact Hessian: indef_strategy 0 -> Gauss-Newton for this and the next 2 iterations;
                 // 1 -> Ipopt's inertia correction, K + delta_w*I with delta_w = 1e-4*max|sc*H_jj| (x100) the first time,
                 // last/3 (x8) afterwards; the accumulators are kept, so a retry is one build_K + one factorisation.
-                T reg = 0, hmax = 0;
+                // in shift mode the previous iteration's delta_w / 3 is the first trial (dropped below 1e-9 * max|H_jj|)
+                T reg = 0;
+                if (use_exact && indef == 1 && dw_spec > (T)0) { reg = dw_spec / (T)3; if (reg < (T)1e-9 * hmax) reg = 0; }
                 bool factored = false, need_condense = true;
                 for (int attempt = 0; attempt < 40; ++attempt) {
                     if (need_condense) {
@@ -595,7 +597,7 @@ template <typename T, int NT> struct Solver {
                     STAMP(4);
                     const bool okc = cholesky();
                     STAMP(5);
-                    if (okc) { factored = true; if (use_exact && reg > 0) dw_last = reg; break; }
+                    if (okc) { factored = true; if (use_exact && reg > 0) dw_last = reg; if (use_exact) dw_spec = reg; break; }
                     if (use_exact && indef == 1) {
                         if (reg == 0) reg = dw_last > 0 ? fmax((T)1e-10 * hmax, dw_last / 3) : (T)1e-4 * hmax;
                         else reg *= dw_last > 0 ? (T)8 : (T)100;
