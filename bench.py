@@ -43,7 +43,8 @@ def measured_traffic_bytes():
     """HBM bytes per 4096-problem dispatch from the committed PMC passes (profiles/r1_pmc_traffic.json), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            return float(json.load(f)["runs"]["v4_256vgpr_spill_free"]["hbm_bytes_per_dispatch"])
+            j = json.load(f)
+            return float(j["runs"][j["current"]]["hbm_bytes_per_dispatch"])
     except Exception:
         return None
 

@@ -95,7 +95,7 @@ template <typename T, int N> struct FastSolver {
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
     static_assert(n + 1 <= 64 && n % 8 == 0, "fast kernel needs 2N + 1 <= 64 and N % 4 == 0");
     typedef typename Real<T>::acc_t acc_t;
-    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64; }
+    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 4 * 64 * NF; }
     // start of column j minus j, so that element (row i, col j) lives at offc(j) + i
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
@@ -104,7 +104,7 @@ template <typename T, int N> struct FastSolver {
     const KP &P;
     int lane;  // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the
                // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
-    T *Lc, *xb, *wb, *cb, *lin, *opb;
+    T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *bub, *blb, *cub, *clb;
     T dinv_l;  // 1 / L[lane][lane] of the current factor
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp;
     T dt, dtc, Lb, rr_, Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
@@ -117,6 +117,9 @@ template <typename T, int N> struct FastSolver {
         cb = wb + 64 * NF;
         lin = cb + 64;
         opb = lin + LIN_STRIDE * (N + 1);
+        cs = opb + 8 * 64;      // wave-uniform scalars that are read once or twice per iteration live here, not in VGPRs
+        ubest = cs + 16;        // last iterate that passed Ipopt's test
+        bub = ubest + 64; blb = bub + 64 * NF; cub = blb + 64 * NF; clb = cub + 64 * NF;  // form bounds, corrector terms
         dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
         Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
         Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
@@ -631,22 +634,23 @@ template <typename T, int N> struct FastSolver {
         const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
         const bool exact = P.hessian == 1;
         T U, Ut, g = 0, du = 0, rhs = 0;
-        T bu[NF], bl[NF], au[NF], lu[NF], ll[NF], aut[NF], w[NF];
+        T au[NF], lu[NF], ll[NF], aut[NF], w[NF];  // form bounds and corrector terms are parked in LDS (bub/blb/cub/clb)
         bool fv[NF];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i]); lu[i] = ll[i] = au[i] = aut[i] = (T)0; }
+        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; { T bu_, bl_; form_bounds(f, bu_, bl_); bub[f] = bu_; blb[f] = bl_; } lu[i] = ll[i] = au[i] = aut[i] = (T)0; }
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
-        T err_last = (T)1e30, Ubest = 0, rds = 0, dw_last = 0, dw_spec = 0, hmax = 0;
+        enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J };
+        cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_AD] = 0; cs[C_J] = 0;
         int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
         bool have_best = false;
-        T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, Jt = 0, alpha = 0, ad = 0, phi0 = 0, dphi = 0, reg = 0;
+        T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, Jt = 0, alpha = 0, reg = 0;
         bool use_exact = exact;
         enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3, RESTEP = 4 };
         const bool pc = P.mu_strategy == 1;
-        T corru[NF], corrl[NF], ya = 0, mu_floor = 0;
+        T ya = 0;
         bool corr_active = false, first_attempt = true;
 #pragma unroll
-        for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
+        for (int i = 0; i < NF; ++i) cub[lane + 64 * i] = clb[lane + 64 * i] = (T)0;
         int mode = FIRST;
         StageF<T> St;
         STAMP_DECL
@@ -667,8 +671,8 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        if (aut[i] > 0) th = fmin(th, (bu[i] - au[i]) / aut[i]);
-                        if (aut[i] < 0) th = fmin(th, (bl[i] + au[i]) / -aut[i]);
+                        if (aut[i] > 0) th = fmin(th, (bub[lane + 64 * i] - au[i]) / aut[i]);
+                        if (aut[i] < 0) th = fmin(th, (blb[lane + 64 * i] + au[i]) / -aut[i]);
                     }
                 th = dpp_min(th) * ((T)1 - (T)P.warm_push);
                 U = Uf + th * dw;
@@ -679,9 +683,9 @@ template <typename T, int N> struct FastSolver {
 #pragma nounroll
         for (;;) {
             asm volatile("" : "+v"(lane));
-            if (mode == FINAL && have_best && !(status == 0 && err_last <= tol)) {
+            if (mode == FINAL && have_best && !(status == 0 && cs[C_ERR] <= tol)) {
                 // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
-                Ut = Ubest; U = Ubest; status = 0;
+                Ut = ubest[lane]; U = Ut; status = 0;
             }
             if (mode != REFACTOR && mode != RESTEP) Jt = eval(Ut, St);  // refactor / restep passes re-use the linearisation of U
             STAMP(9);
@@ -692,34 +696,36 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T a_ = bu[i] - (au[i] + alpha * aut[i]), b_ = bl[i] + (au[i] + alpha * aut[i]);
+                        const T a_ = bub[lane + 64 * i] - (au[i] + alpha * aut[i]), b_ = blb[lane + 64 * i] + (au[i] + alpha * aut[i]);
                         if (!(a_ > 0) || !(b_ > 0)) okp = false; else lgt += log(a_ * b_);
                     }
                 okp = __all(okp);
                 const T phi = sc * Jt - mu * dpp_sum(lgt);
-                if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi)) {
+                const T phi0 = cs[C_PHI0];
+                if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * cs[C_DPHI])) {
                     // safeguard: the corrected direction is tried at the full step only; redo the step without the corrector term
                     if (corr_active) { mode = RESTEP; Ut = U; continue; }
                     if (++ls >= P.max_ls) {
-                        status = err_last <= (T)100 * tol ? 0 : 3; mode = FINAL; Ut = U; continue;  // acceptable level
+                        status = cs[C_ERR] <= (T)100 * tol ? 0 : 3; mode = FINAL; Ut = U; continue;  // acceptable level
                     }
                     alpha *= (T)0.5;
                     Ut = U + alpha * du;
                     continue;
                 }
                 // accepted: dual step from the pre-step slacks (au still holds A*U_old)
+                const T ad = cs[C_AD];
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T su = bu[i] - au[i], sl = bl[i] + au[i];
-                        lu[i] += ad * ((mu - corru[i] - lu[i] * su) / su + lu[i] / su * aut[i]);
-                        ll[i] += ad * ((mu - corrl[i] - ll[i] * sl) / sl - ll[i] / sl * aut[i]);
+                        const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i];
+                        lu[i] += ad * ((mu - cub[lane + 64 * i] - lu[i] * su) / su + lu[i] / su * aut[i]);
+                        ll[i] += ad * ((mu - clb[lane + 64 * i] - ll[i] * sl) / sl - ll[i] / sl * aut[i]);
                     }
             }
             const bool restep = mode == RESTEP;
             if (!restep) {
             if (mode != REFACTOR) {
-            U = Ut; J = Jt;
+            U = Ut; cs[C_J] = Jt;
             g = linearize(St, exact);
             STAMP(1);
                 forms_apply(U, au);
@@ -727,12 +733,12 @@ template <typename T, int N> struct FastSolver {
                     const T gm = dpp_max(fabs(g));
                     sc = gm > (T)100 ? (T)100 / gm : (T)1;  // Ipopt nlp_scaling_max_gradient
 #pragma unroll
-                    for (int i = 0; i < NF; ++i) { lu[i] = fv[i] ? mu / (bu[i] - au[i]) : (T)0; ll[i] = fv[i] ? mu / (bl[i] + au[i]) : (T)0; }
+                    for (int i = 0; i < NF; ++i) { lu[i] = fv[i] ? mu / (bub[lane + 64 * i] - au[i]) : (T)0; ll[i] = fv[i] ? mu / (blb[lane + 64 * i] + au[i]) : (T)0; }
                 } else {
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
                         if (fv[i]) {
-                            const T su = bu[i] - au[i], sl = bl[i] + au[i];
+                            const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i];
                             lu[i] = fmax(fmin(lu[i], kappa_sigma * mu / su), mu / (kappa_sigma * su));
                             ll[i] = fmax(fmin(ll[i], kappa_sigma * mu / sl), mu / (kappa_sigma * sl));
                         }
@@ -747,32 +753,32 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T cu = (bu[i] - au[i]) * lu[i], cl = (bl[i] + au[i]) * ll[i];
+                        const T cu = (bub[lane + 64 * i] - au[i]) * lu[i], cl = (blb[lane + 64 * i] + au[i]) * ll[i];
                         lsum += lu[i] + ll[i]; gap += cu + cl; cm0 = fmax(cm0, fmax(cu, cl));
                     }
                 const T rdm = dpp_max(fabs(rd));
                 lsum = dpp_sum(lsum); cm0 = dpp_max(cm0); gap = dpp_sum(gap);
                 const T s_d = fmax(s_max, lsum / (T)(2 * nf)) / s_max;
                 const T err0 = fmax(rdm, cm0) / s_d;
-                const T gap_lim = gap_tol * fmax((T)1, fabs(J));
-                err_last = err0; rds = rdm / s_d;
+                const T gap_lim = gap_tol * fmax((T)1, fabs(Jt));
+                cs[C_ERR] = err0; cs[C_RDS] = rdm / s_d;
                 // Ipopt's test (+ gap bound, pursued for at most 1 more iteration once Ipopt's test is met), or
                 // Ipopt's "acceptable level" (error <= 100*tol for 15 iterations in a row)
                 bool done = false;
-                if (err0 <= tol) { Ubest = U; have_best = true; }  // last iterate passing Ipopt's test
+                if (err0 <= tol) { ubest[lane] = U; have_best = true; }  // last iterate passing Ipopt's test
                 if (err0 <= tol) {
                     if (gap / sc <= gap_lim || n_polish >= 1) done = true; else ++n_polish;
                 } else if (n_polish > 0 && ++n_polish > 1) done = true;
                 n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
                 if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
                 const T mu_min = fmax(tol * (T)1e-2, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
-                mu_floor = mu_min;
+                cs[C_MUF] = mu_min;
 #pragma nounroll
                 for (; !pc;) {  // monotone barrier update (mu_strategy 0)
                     T cmu = 0;
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
-                        if (fv[i]) cmu = fmax(cmu, fmax(fabs((bu[i] - au[i]) * lu[i] - mu), fabs((bl[i] + au[i]) * ll[i] - mu)));
+                        if (fv[i]) cmu = fmax(cmu, fmax(fabs((bub[lane + 64 * i] - au[i]) * lu[i] - mu), fabs((blb[lane + 64 * i] + au[i]) * ll[i] - mu)));
                     cmu = dpp_max(cmu);
                     if (fmax(rdm, cmu) / s_d <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, mu * sqrt(mu)));
                     else break;
@@ -780,14 +786,14 @@ template <typename T, int N> struct FastSolver {
                 use_exact = exact && gn_hold == 0; reg = 0; attempt = 0;  // GN is held for 2 iterations after an indefinite exact Hessian
                 if (gn_hold > 0) --gn_hold;
                 // in shift mode the previous iteration's delta_w / 3 is the first trial (dropped below 1e-9 * max|H_jj|)
-                if (use_exact && indef == 1 && dw_spec > (T)0) { reg = dw_spec / (T)3; if (reg < (T)1e-9 * hmax) reg = 0; }
+                if (use_exact && indef == 1 && cs[C_DWS] > (T)0) { reg = cs[C_DWS] / (T)3; if (reg < (T)1e-9 * cs[C_HMAX]) reg = 0; }
                 first_attempt = true;
                 STAMP(2);
             }
             // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
             rhs = -sc * g;
 #pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / (bu[i] - au[i]) + ll[i] / (bl[i] + au[i]) : (T)0;
+            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / (bub[lane + 64 * i] - au[i]) + ll[i] / (blb[lane + 64 * i] + au[i]) : (T)0;
             stage_form_weights(w);
             STAMP(6);
             bool factored;
@@ -801,7 +807,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[ti * (ti + 1) / 2 + ti][r]));
-                    hmax = dpp_max(hm);
+                    cs[C_HMAX] = dpp_max(hm);
                 }
                 first_attempt = false;
                 STAMP(3);
@@ -816,6 +822,7 @@ template <typename T, int N> struct FastSolver {
                 // 2 -> 0 until the second failure, 1 from then on (Gauss-Newton leaves a saddle only slowly)
                 if (++attempt >= 40) { status = 3; mode = FINAL; Ut = U; continue; }
                 if (use_exact && indef == 1) {
+                    const T hmax = cs[C_HMAX], dw_last = cs[C_DWL];
                     if (reg == (T)0) reg = dw_last > (T)0 ? fmax((T)1e-10 * hmax, dw_last / (T)3) : (T)1e-4 * hmax;
                     else reg *= dw_last > (T)0 ? (T)8 : (T)100;
                     if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; }
@@ -826,11 +833,11 @@ template <typename T, int N> struct FastSolver {
                 mode = REFACTOR; Ut = U;
                 continue;
             }
-            if (use_exact && reg > (T)0) dw_last = reg;
-            if (use_exact) dw_spec = reg;
+            if (use_exact && reg > (T)0) cs[C_DWL] = reg;
+            if (use_exact) cs[C_DWS] = reg;
             ya = lane < n ? Lc[offc_rt(lane) + n] : (T)0;  // L^{-1}(-sc*g)
 #pragma unroll
-            for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
+            for (int i = 0; i < NF; ++i) cub[lane + 64 * i] = clb[lane + 64 * i] = (T)0;
             corr_active = false;
             if (pc) {
                 // Mehrotra predictor: affine-scaling step on the same factor -> this iteration's barrier target
@@ -840,7 +847,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T su = bu[i] - au[i], sl = bl[i] + au[i], dsu = -aut[i], dsl = aut[i];
+                        const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i], dsu = -aut[i], dsl = aut[i];
                         const T dlu = -lu[i] - lu[i] / su * dsu, dll = -ll[i] - ll[i] / sl * dsl;
                         if (dsu < 0) apa = fmin(apa, -su / dsu);
                         if (dsl < 0) apa = fmin(apa, -sl / dsl);
@@ -852,38 +859,38 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T su = bu[i] - au[i], sl = bl[i] + au[i], dsu = -aut[i], dsl = aut[i];
+                        const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i], dsu = -aut[i], dsl = aut[i];
                         const T dlu = -lu[i] - lu[i] / su * dsu, dll = -ll[i] - ll[i] / sl * dsl;
                         muaff += (su + apa * dsu) * (lu[i] + ada * dlu) + (sl + apa * dsl) * (ll[i] + ada * dll);
-                        corru[i] = dsu * dlu; corrl[i] = dsl * dll;
+                        cub[lane + 64 * i] = dsu * dlu; clb[lane + 64 * i] = dsl * dll;
                     }
                 mucur = dpp_sum(mucur) / (T)(2 * nf); muaff = dpp_sum(muaff) / (T)(2 * nf);
                 const T r3 = muaff / mucur;
-                mu = fmax(mu_floor, fmin((T)1, r3 * r3 * r3) * mucur);
-                mu = fmax(mu, fmin(mucur, rds / (T)1e3));  // no barrier target far below the dual infeasibility
+                mu = fmax(cs[C_MUF], fmin((T)1, r3 * r3 * r3) * mucur);
+                mu = fmax(mu, fmin(mucur, cs[C_RDS] / (T)1e3));  // no barrier target far below the dual infeasibility
                 corr_active = true;
                 STAMP(7);
             }
             } else {  // RESTEP: same factor, corrector term dropped
 #pragma unroll
-                for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
+                for (int i = 0; i < NF; ++i) cub[lane + 64 * i] = clb[lane + 64 * i] = (T)0;
                 corr_active = false;
             }
             // centering (+ corrector) part of the step: du = K^{-1}(-sc*g - A^T((mu - corr)/s_u - (mu - corr)/s_l))
 #pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - corru[i]) / (bu[i] - au[i]) - (mu - corrl[i]) / (bl[i] + au[i])) : (T)0;
+            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - cub[lane + 64 * i]) / (bub[lane + 64 * i] - au[i]) - (mu - clb[lane + 64 * i]) / (blb[lane + 64 * i] + au[i])) : (T)0;
             du = back_subst(ya + fwd_subst(forms_applyT(w)));
             STAMP(15);
             forms_apply(du, aut);
             const T tau = fmax(tau_min, (T)1 - mu);
             T ap = 1, lg = 0, gw = 0;
-            ad = 1;
+            T ad = 1;
 #pragma unroll
             for (int i = 0; i < NF; ++i)
                 if (fv[i]) {
-                    const T su = bu[i] - au[i], sl = bl[i] + au[i], dsu = -aut[i], dsl = aut[i];
-                    const T dlu = (mu - corru[i] - lu[i] * su) / su - lu[i] / su * dsu;
-                    const T dll = (mu - corrl[i] - ll[i] * sl) / sl - ll[i] / sl * dsl;
+                    const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i], dsu = -aut[i], dsl = aut[i];
+                    const T dlu = (mu - cub[lane + 64 * i] - lu[i] * su) / su - lu[i] / su * dsu;
+                    const T dll = (mu - clb[lane + 64 * i] - ll[i] * sl) / sl - ll[i] / sl * dsl;
                     gw += (mu / su - mu / sl) * aut[i];
                     if (dsu < 0) ap = fmin(ap, -tau * su / dsu);
                     if (dsl < 0) ap = fmin(ap, -tau * sl / dsl);
@@ -891,9 +898,9 @@ template <typename T, int N> struct FastSolver {
                     if (dll < 0) ad = fmin(ad, -tau * ll[i] / dll);
                     lg += log(su * sl);
                 }
-            ap = dpp_min(ap); ad = dpp_min(ad);
-            phi0 = sc * J - mu * dpp_sum(lg);
-            dphi = dpp_sum((lane < n ? sc * g * du : (T)0) + gw);  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
+            ap = dpp_min(ap); cs[C_AD] = dpp_min(ad);
+            cs[C_PHI0] = sc * cs[C_J] - mu * dpp_sum(lg);
+            cs[C_DPHI] = dpp_sum((lane < n ? sc * g * du : (T)0) + gw);  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
             alpha = ap; ls = 0;
             Ut = U + alpha * du;
             mode = TRIAL;
@@ -907,7 +914,7 @@ template <typename T, int N> struct FastSolver {
         for (int i = 0; i < NF; ++i)
             if (fv[i]) {
                 const int f = lane + 64 * i;
-                viol = fmax(viol, fmax(au[i] - (bu[i] - form_relax(f, true)), -au[i] - (bl[i] - form_relax(f, false))));
+                viol = fmax(viol, fmax(au[i] - (bub[lane + 64 * i] - form_relax(f, true)), -au[i] - (blb[lane + 64 * i] - form_relax(f, false))));
             }
         viol = dpp_max(viol);
         if (lane < n) {
