@@ -410,6 +410,21 @@ template <typename T, int NT> struct Solver {
     DEV bool interior_point(T (&Uf)[NV])
     {
         const T relax = (T)P.relax;
+        // first guess of the solution inside the bounds (oracle/kmpc_condensed.c::interior_point): accelerations approach
+        // the reference speed (time constant 1 s), steering the kinematic feed-forward of the reference's mean curvature;
+        // reference points 1..N only -- point 0 is a dead input (Q3)
+        const T frac = (T)0.6, rr = (T)P.r;
+        T len, kap;
+        {
+            const T rxn = __shfl_down(rx, 1), ryn = __shfl_down(ry, 1);
+            const T seg = (lane >= 1 && lane < N) ? sqrt((rxn - rx) * (rxn - rx) + (ryn - ry) * (ryn - ry)) : (T)0;
+            len = wave_sum(seg);
+            kap = (readlane_(rp, N) - readlane_(rp, 1)) / fmax(len, (T)1e-6);
+        }
+        const T vref = len / ((T)(N - 1) * dt);
+        const T sb = fmin(fmax((T)P.L_b * kap, (T)-0.9), (T)0.9);
+        const T dff = fmin(fmax(atan(tan(asin(sb)) / rr), -frac * (T)P.steer_max), frac * (T)P.steer_max);
+        const T aff = fmin(fmax(vref - v0, -frac * (T)P.a_max), frac * (T)P.a_max);
         T u0[2];
         bool ok = true;
 #pragma unroll
@@ -425,22 +440,25 @@ template <typename T, int NT> struct Solver {
             }
             if (!(lo < hi)) ok = false;
             const T push = (T)0.25 * (hi - lo);
-            u0[j] = fmin(fmax((T)0, lo + push), hi - push);
+            u0[j] = fmin(fmax(j ? dff : aff, lo + push), hi - push);
         }
         const T vm = fmin((T)1, (T)0.25 * ((T)P.v_max - (T)P.v_min)), acap = (T)0.5 * (T)P.a_max;
-        T v = v0 + dt * u0[0];
+        const T astep = frac * (T)P.a_dmax * dt, dstep = frac * (T)P.steer_dmax * dt;
+        T v = v0 + dt * u0[0], ap = u0[0], dp = u0[1];
 #pragma unroll
         for (int i = 0; i < NV; ++i) Uf[i] = (T)0;
         if (lane == 0) Uf[0] = u0[0];
         if (lane == 1) Uf[0] = u0[1];
         for (int k = 1; k < N; ++k) {  // uniform scalar recurrence, N steps
-            T a = (T)0;
-            if (v < (T)P.v_min + vm) a = fmin((T)P.v_min + vm - v, acap);
-            else if (v > (T)P.v_max - vm) a = fmax((T)P.v_max - vm - v, -acap);
+            T a = fmin(fmax(vref - v, -frac * (T)P.a_max), frac * (T)P.a_max);
+            a = fmin(fmax(a, ap - astep), ap + astep);
+            if (v + dt * a < (T)P.v_min + vm) a = fmin((T)P.v_min + vm - v, acap);
+            else if (v + dt * a > (T)P.v_max - vm) a = fmax((T)P.v_max - vm - v, -acap);
+            const T d = fmin(fmax(dff, dp - dstep), dp + dstep);
             const int j = 2 * k;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) if (lane + 64 * i == j) Uf[i] = a;
-            v += dt * a;
+            for (int i = 0; i < NV; ++i) { if (lane + 64 * i == j) Uf[i] = a; if (lane + 64 * i == j + 1) Uf[i] = d; }
+            v += dt * a; ap = a; dp = d;
         }
         return ok;
     }
