@@ -160,6 +160,17 @@ int32_t kmpc_waypoints_batch(kmpc_path *p, int32_t B, int32_t horizon, double tr
                              void *stream);
 const char *kmpc_path_last_error(kmpc_path *p);
 
+/* ---- closed-loop simulator --------------------------------------------------------
+ * Replaces, for B simulated vehicles at once, `n_updates` passes of VehicleSimulator._update_vehicle_model
+ * (scripts/vehicle_simulator.py:58-107: dynamic bicycle, linear tyres, 10 Euler sub-steps of 1 ms per pass, heading
+ * wrapped to [-pi, pi)) including the actuator lag of _update_low_level_control (:109-113).  n_updates = 10 is one
+ * 10 Hz control period of mpc_cmd_pub.jl:87.
+ *   state [B,8] fp64 DEVICE, in/out: X, Y, psi, vx, vy, wz, acc, df   (the simulator's attributes, :18-34;
+ *                                    state_est publishes x=X, y=Y, psi, v=vx, a=acc, df -- :41-48)
+ *   cmd   [B,2] fp64 DEVICE: accel_cmd, steer_angle_cmd of MPC_cmd (:52-55)
+ * Asynchronous on `stream` (NULL = the device's default stream).  Errors: negative code, text in kmpc_last_error(NULL). */
+int32_t kmpc_sim_advance_batch(int32_t device, int32_t B, void *state, const void *cmd, int32_t n_updates, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,8 @@ class Config(C.Structure):
 EXPORTS = ["kmpc_abi_version", "kmpc_config_default", "kmpc_create", "kmpc_destroy", "kmpc_set_cost",
            "kmpc_get_cost", "kmpc_solve_batch", "kmpc_solve_batch_host", "kmpc_last_error",
            "kmpc_debug_condense", "kmpc_debug_mfma_probe",
-           "kmpc_path_create", "kmpc_path_destroy", "kmpc_waypoints_batch", "kmpc_path_last_error"]
+           "kmpc_path_create", "kmpc_path_destroy", "kmpc_waypoints_batch", "kmpc_path_last_error",
+           "kmpc_sim_advance_batch"]
 
 _lib = None
 
@@ -62,6 +63,7 @@ def load():
     L.kmpc_waypoints_batch.argtypes = [vp, i32, i32, C.c_double, vp, vp, vp, vp, vp, vp]
     L.kmpc_path_last_error.argtypes = [vp]
     L.kmpc_path_last_error.restype = C.c_char_p
+    L.kmpc_sim_advance_batch.argtypes = [i32, i32, vp, vp, i32, vp]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

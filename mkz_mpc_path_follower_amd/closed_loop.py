@@ -1,0 +1,51 @@
+"""Closed loop of launch/sim_path_follow.launch for B vehicles at once, entirely on the device:
+state_est (vehicle_sim.VehicleSimulator) -> waypoints (ref_traj.GPSRefTrajectory) -> MPC (solver.BatchMPC, warm-started)
+-> MPC_cmd -> simulator.  One `step()` is one pass of the 10 Hz loop of mpc_cmd_pub.jl:88-153 for every vehicle,
+followed by 0.1 s of plant time (10 model updates at 100 Hz, vehicle_simulator.py:24-26).
+
+Protocol details kept from the reference node: the command is published regardless of the solver status (Q7); the
+rate-limit anchor is the last *command*, not the measured actuator state (:140, Q7); the stop flag of the waypoint
+helper latches and overrides the command with accel -1.0 / steer 0.0 (:100-103, :148-153), per vehicle; warm start
+from the previous primal solution (JuMP keeps values, Q9).
+"""
+import torch
+
+from .solver import BatchMPC
+
+
+class ClosedLoop:
+    def __init__(self, grt, sim, N=8, target_vel=0.0, track_with_time=False, weights=(9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0),
+                 mpc=None, **options):
+        if grt.traj_horizon != N:
+            raise ValueError("waypoint horizon %d != MPC horizon %d (Q10: the reference passes them separately)" % (grt.traj_horizon, N))
+        self.grt, self.sim, self.N = grt, sim, int(N)
+        self.B = sim.B
+        self.mpc = mpc if mpc is not None else BatchMPC(N=N, dtype=torch.float64, device=sim.device.index, weights=weights, **options)
+        self.track_with_time = track_with_time
+        self.des_speed = float(target_vel) if target_vel > 0.0 else 0.0  # mpc_cmd_pub.jl:58-62
+        dev = sim.device
+        self.v_target = torch.full((self.B,), self.des_speed, dtype=torch.float64, device=dev)
+        self.u_prev = torch.zeros((self.B, 2), dtype=torch.float64, device=dev)       # (acc, d_f): update_current_input starts at 0
+        self.warm_U = torch.zeros((self.B, self.N, 2), dtype=torch.float64, device=dev)
+        self.command_stop = torch.zeros((self.B,), dtype=torch.bool, device=dev)
+        self.have_warm = False
+        self.out = None
+        self.k = 0
+
+    def step(self, plant_updates=10):
+        st = self.sim.state
+        pose = st[:, 0:3].contiguous()
+        ref, stop = self.grt.get_waypoints_batch(pose, None if self.track_with_time else self.v_target)
+        self.command_stop |= stop.bool()                                            # :100-103
+        z0 = st[:, 0:4].contiguous()                                                # x, y, psi, v = vx  (state_est, :43-46 of the simulator)
+        self.out = self.mpc.solve(z0, ref, self.v_target, self.u_prev, warm_U=self.warm_U, warm=self.have_warm, out=self.out)
+        self.have_warm = True
+        u0 = self.out["u0"]
+        stopc = self.command_stop.unsqueeze(1)
+        stop_cmd = torch.tensor([-1.0, 0.0], dtype=torch.float64, device=u0.device)
+        cmd = torch.where(stopc, stop_cmd, u0)                                       # :148-153
+        self.u_prev = torch.where(stopc, self.u_prev, u0)                            # :140 (only on the solve branch)
+        self.sim.cmd.copy_(cmd)
+        self.sim._update_vehicle_model(plant_updates)
+        self.k += 1
+        return dict(ref=ref, cmd=cmd, status=self.out["status"], iters=self.out["iters"], cost=self.out["cost"])

@@ -17,6 +17,7 @@ template <typename T> hipError_t kmpc_launch_condense(const KP &, const KDbg<T> 
 template <typename T> hipError_t kmpc_launch_probe(const T *, const T *, T *, hipStream_t);
 template <typename T> bool kmpc_fast_available(int N);
 template <typename T> hipError_t kmpc_launch_solve_fast(const KP &, const KIO<T> &, hipStream_t);
+hipError_t kmpc_launch_sim(int, double *, const double *, int, hipStream_t);
 template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, const T *, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
 
 struct kmpc_handle {
@@ -376,3 +377,14 @@ extern "C" int32_t kmpc_waypoints_batch(kmpc_path *p, int32_t B, int32_t horizon
 }
 
 extern "C" const char *kmpc_path_last_error(kmpc_path *p) { return p ? p->err.c_str() : g_create_err.c_str(); }
+
+// ---- closed-loop simulator (kmpc_sim.hip) ------------------------------------------------------------------------
+extern "C" int32_t kmpc_sim_advance_batch(int32_t device, int32_t B, void *state, const void *cmd, int32_t n_updates, void *stream)
+{
+    if (B < 0 || n_updates < 0 || (B > 0 && (!state || !cmd))) return fail(nullptr, KMPC_ERR_ARG, "kmpc_sim_advance_batch: bad argument (B=%d, n_updates=%d)", B, n_updates);
+    if (B == 0 || n_updates == 0) return KMPC_OK;
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, KMPC_ERR_HIP, "kmpc_sim_advance_batch: hipSetDevice(%d) failed", device);
+    const hipError_t e = kmpc_launch_sim(B, (double *)state, (const double *)cmd, n_updates, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, KMPC_ERR_HIP, "kmpc_sim_advance_batch: %s", hipGetErrorString(e));
+    return KMPC_OK;
+}

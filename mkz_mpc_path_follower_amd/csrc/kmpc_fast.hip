@@ -95,7 +95,7 @@ template <typename T, int N> struct FastSolver {
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
     static_assert(n + 1 <= 64 && n % 8 == 0, "fast kernel needs 2N + 1 <= 64 and N % 4 == 0");
     typedef typename Real<T>::acc_t acc_t;
-    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 4 * 64 * NF; }
+    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 2 * 64 * NF; }
     // start of column j minus j, so that element (row i, col j) lives at offc(j) + i
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
@@ -104,9 +104,9 @@ template <typename T, int N> struct FastSolver {
     const KP &P;
     int lane;  // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the
                // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
-    T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *bub, *blb, *cub, *clb;
+    T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *cub, *clb;
     T dinv_l;  // 1 / L[lane][lane] of the current factor
-    T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp;
+    T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
     T dt, dtc, Lb, rr_, Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
 
     DEV FastSolver(const KP &p, unsigned char *smem) : P(p), lane(threadIdx.x)
@@ -119,7 +119,7 @@ template <typename T, int N> struct FastSolver {
         opb = lin + LIN_STRIDE * (N + 1);
         cs = opb + 8 * 64;      // wave-uniform scalars that are read once or twice per iteration live here, not in VGPRs
         ubest = cs + 16;        // last iterate that passed Ipopt's test
-        bub = ubest + 64; blb = bub + 64 * NF; cub = blb + 64 * NF; clb = cub + 64 * NF;  // form bounds, corrector terms
+        cub = ubest + 64; clb = cub + 64 * NF;  // corrector terms
         dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
         Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
         Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
@@ -127,13 +127,17 @@ template <typename T, int N> struct FastSolver {
 
     DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)
     {
-        x0 = z0[4 * (size_t)b]; y0 = z0[4 * (size_t)b + 1]; psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
+        // the NLP is invariant under a translation of (x, y): solve it in vehicle-centred coordinates (recorded paths live hundreds
+        // of metres from their origin; positions would carry ~1e-13 m of rounding = ~1e-12 in the cost, above the Armijo
+        // decrease of the last iterations); predictions are shifted back on output
+        xoff = z0[4 * (size_t)b]; yoff = z0[4 * (size_t)b + 1]; x0 = (T)0; y0 = (T)0;
+        psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
         vt = vtp[b];
         up0 = upp[2 * (size_t)b]; up1 = upp[2 * (size_t)b + 1];
         rx = ry = rp = (T)0;
         if (lane <= N) {
             const T *r = ref + ((size_t)b * (N + 1) + lane) * 3;
-            rx = r[0]; ry = r[1]; rp = r[2];
+            rx = r[0] - xoff; ry = r[1] - yoff; rp = r[2];
         }
     }
 
@@ -593,7 +597,7 @@ template <typename T, int N> struct FastSolver {
     DEV bool interior_point(T &Uf)
     {
         const T relax = (T)P.relax;
-        // first guess of the solution inside the bounds (oracle/kmpc_condensed.c::interior_point): accelerations approach
+        // first guess of the solution inside the bounds (same rule as the CPU checker): accelerations approach
         // the reference speed (time constant 1 s), steering the kinematic feed-forward of the reference's mean curvature;
         // reference points 1..N only -- point 0 is a dead input (Q3)
         const T frac = (T)0.6, rr = (T)P.r;
@@ -653,10 +657,12 @@ template <typename T, int N> struct FastSolver {
         const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
         const bool exact = P.hessian == 1;
         T U, Ut, g = 0, du = 0, rhs = 0;
-        T au[NF], lu[NF], ll[NF], aut[NF], w[NF];  // form bounds and corrector terms are parked in LDS (bub/blb/cub/clb)
+        // slacks are iterates, advanced by s -/+ alpha * a_f^T du (as in Ipopt): recomputing b - a_f^T U would lose 7 digits to
+        // cancellation once an active slack is ~1e-9; corrector terms are parked in LDS (cub/clb)
+        T sup[NF], slo[NF], lu[NF], ll[NF], aut[NF], w[NF];
         bool fv[NF];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; { T bu_, bl_; form_bounds(f, bu_, bl_); bub[f] = bu_; blb[f] = bl_; } lu[i] = ll[i] = au[i] = aut[i] = (T)0; }
+        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; lu[i] = ll[i] = sup[i] = slo[i] = aut[i] = (T)0; }
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
         enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J };
         cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_AD] = 0; cs[C_J] = 0;
@@ -684,14 +690,16 @@ template <typename T, int N> struct FastSolver {
                 mode = FINAL;
             } else if (P.warm && io.warmU) {
                 const T dw = lane < n ? io.warmU[(size_t)b * n + lane] - Uf : (T)0;
-                forms_apply(Uf, au);
+                forms_apply(Uf, w);
                 forms_apply(dw, aut);
                 T th = 1;
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        if (aut[i] > 0) th = fmin(th, (bub[lane + 64 * i] - au[i]) / aut[i]);
-                        if (aut[i] < 0) th = fmin(th, (blb[lane + 64 * i] + au[i]) / -aut[i]);
+                        T bu_, bl_;
+                        form_bounds(lane + 64 * i, bu_, bl_);
+                        if (aut[i] > 0) th = fmin(th, (bu_ - w[i]) / aut[i]);
+                        if (aut[i] < 0) th = fmin(th, (bl_ + w[i]) / -aut[i]);
                     }
                 th = dpp_min(th) * ((T)1 - (T)P.warm_push);
                 U = Uf + th * dw;
@@ -715,7 +723,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T a_ = bub[lane + 64 * i] - (au[i] + alpha * aut[i]), b_ = blb[lane + 64 * i] + (au[i] + alpha * aut[i]);
+                        const T a_ = sup[i] - alpha * aut[i], b_ = slo[i] + alpha * aut[i];
                         if (!(a_ > 0) || !(b_ > 0)) okp = false; else lgt += log(a_ * b_);
                     }
                 okp = __all(okp);
@@ -731,14 +739,16 @@ template <typename T, int N> struct FastSolver {
                     Ut = U + alpha * du;
                     continue;
                 }
-                // accepted: dual step from the pre-step slacks (au still holds A*U_old)
+                // accepted: dual step from the pre-step slacks, then the slacks advance with the step
                 const T ad = cs[C_AD];
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i];
+                        const T su = sup[i], sl = slo[i];
                         lu[i] += ad * ((mu - cub[lane + 64 * i] - lu[i] * su) / su + lu[i] / su * aut[i]);
                         ll[i] += ad * ((mu - clb[lane + 64 * i] - ll[i] * sl) / sl - ll[i] / sl * aut[i]);
+                        sup[i] = su - alpha * aut[i];
+                        slo[i] = sl + alpha * aut[i];
                     }
             }
             const bool restep = mode == RESTEP;
@@ -747,17 +757,23 @@ template <typename T, int N> struct FastSolver {
             U = Ut; cs[C_J] = Jt;
             g = linearize(St, exact);
             STAMP(1);
-                forms_apply(U, au);
                 if (mode == FIRST) {
+                    forms_apply(U, w);
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) {
+                        T bu_, bl_;
+                        form_bounds(lane + 64 * i, bu_, bl_);
+                        sup[i] = bu_ - w[i]; slo[i] = bl_ + w[i];
+                    }
                     const T gm = dpp_max(fabs(g));
                     sc = gm > (T)100 ? (T)100 / gm : (T)1;  // Ipopt nlp_scaling_max_gradient
 #pragma unroll
-                    for (int i = 0; i < NF; ++i) { lu[i] = fv[i] ? mu / (bub[lane + 64 * i] - au[i]) : (T)0; ll[i] = fv[i] ? mu / (blb[lane + 64 * i] + au[i]) : (T)0; }
+                    for (int i = 0; i < NF; ++i) { lu[i] = fv[i] ? mu / sup[i] : (T)0; ll[i] = fv[i] ? mu / slo[i] : (T)0; }
                 } else {
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
                         if (fv[i]) {
-                            const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i];
+                            const T su = sup[i], sl = slo[i];
                             lu[i] = fmax(fmin(lu[i], kappa_sigma * mu / su), mu / (kappa_sigma * su));
                             ll[i] = fmax(fmin(ll[i], kappa_sigma * mu / sl), mu / (kappa_sigma * sl));
                         }
@@ -772,7 +788,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T cu = (bub[lane + 64 * i] - au[i]) * lu[i], cl = (blb[lane + 64 * i] + au[i]) * ll[i];
+                        const T cu = sup[i] * lu[i], cl = slo[i] * ll[i];
                         lsum += lu[i] + ll[i]; gap += cu + cl; cm0 = fmax(cm0, fmax(cu, cl));
                     }
                 const T rdm = dpp_max(fabs(rd));
@@ -797,7 +813,7 @@ template <typename T, int N> struct FastSolver {
                     T cmu = 0;
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
-                        if (fv[i]) cmu = fmax(cmu, fmax(fabs((bub[lane + 64 * i] - au[i]) * lu[i] - mu), fabs((blb[lane + 64 * i] + au[i]) * ll[i] - mu)));
+                        if (fv[i]) cmu = fmax(cmu, fmax(fabs(sup[i] * lu[i] - mu), fabs(slo[i] * ll[i] - mu)));
                     cmu = dpp_max(cmu);
                     if (fmax(rdm, cmu) / s_d <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, mu * sqrt(mu)));
                     else break;
@@ -812,7 +828,7 @@ template <typename T, int N> struct FastSolver {
             // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
             rhs = -sc * g;
 #pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / (bub[lane + 64 * i] - au[i]) + ll[i] / (blb[lane + 64 * i] + au[i]) : (T)0;
+            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / sup[i] + ll[i] / slo[i] : (T)0;
             stage_form_weights(w);
             STAMP(6);
             bool factored;
@@ -866,7 +882,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i], dsu = -aut[i], dsl = aut[i];
+                        const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
                         const T dlu = -lu[i] - lu[i] / su * dsu, dll = -ll[i] - ll[i] / sl * dsl;
                         if (dsu < 0) apa = fmin(apa, -su / dsu);
                         if (dsl < 0) apa = fmin(apa, -sl / dsl);
@@ -878,7 +894,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i], dsu = -aut[i], dsl = aut[i];
+                        const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
                         const T dlu = -lu[i] - lu[i] / su * dsu, dll = -ll[i] - ll[i] / sl * dsl;
                         muaff += (su + apa * dsu) * (lu[i] + ada * dlu) + (sl + apa * dsl) * (ll[i] + ada * dll);
                         cub[lane + 64 * i] = dsu * dlu; clb[lane + 64 * i] = dsl * dll;
@@ -897,7 +913,7 @@ template <typename T, int N> struct FastSolver {
             }
             // centering (+ corrector) part of the step: du = K^{-1}(-sc*g - A^T((mu - corr)/s_u - (mu - corr)/s_l))
 #pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - cub[lane + 64 * i]) / (bub[lane + 64 * i] - au[i]) - (mu - clb[lane + 64 * i]) / (blb[lane + 64 * i] + au[i])) : (T)0;
+            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - cub[lane + 64 * i]) / sup[i] - (mu - clb[lane + 64 * i]) / slo[i]) : (T)0;
             du = back_subst(ya + fwd_subst(forms_applyT(w)));
             STAMP(15);
             forms_apply(du, aut);
@@ -907,7 +923,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
             for (int i = 0; i < NF; ++i)
                 if (fv[i]) {
-                    const T su = bub[lane + 64 * i] - au[i], sl = blb[lane + 64 * i] + au[i], dsu = -aut[i], dsl = aut[i];
+                    const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
                     const T dlu = (mu - cub[lane + 64 * i] - lu[i] * su) / su - lu[i] / su * dsu;
                     const T dll = (mu - clb[lane + 64 * i] - ll[i] * sl) / sl - ll[i] / sl * dsl;
                     gw += (mu / su - mu / sl) * aut[i];
@@ -927,13 +943,15 @@ template <typename T, int N> struct FastSolver {
         }
         STAMP(10);
         // ---- outputs (St / Jt are the evaluation of the returned U) ------------------------------------
-        forms_apply(U, au);
+        forms_apply(U, w);
         T viol = -(T)1e30;
 #pragma unroll
         for (int i = 0; i < NF; ++i)
             if (fv[i]) {
                 const int f = lane + 64 * i;
-                viol = fmax(viol, fmax(au[i] - (bub[lane + 64 * i] - form_relax(f, true)), -au[i] - (blb[lane + 64 * i] - form_relax(f, false))));
+                T bu_, bl_;
+                form_bounds(f, bu_, bl_);
+                viol = fmax(viol, fmax(w[i] - (bu_ - form_relax(f, true)), -w[i] - (bl_ - form_relax(f, false))));
             }
         viol = dpp_max(viol);
         if (lane < n) {
@@ -943,7 +961,7 @@ template <typename T, int N> struct FastSolver {
         }
         if (io.outX && lane <= N) {
             T *o = io.outX + ((size_t)b * (N + 1) + lane) * 4;
-            o[0] = St.x; o[1] = St.y; o[2] = St.psi; o[3] = St.v;
+            o[0] = St.x + xoff; o[1] = St.y + yoff; o[2] = St.psi; o[3] = St.v;
         }
         STAMP(11);
         STAMP_OUT(io.stamps, b);

@@ -40,7 +40,7 @@ template <typename T, int NT> struct Solver {
     const int lane, N, n, R, nf, ld;
     T *Km, *stg, *xb, *wb, *cb, *dinv;
     // problem data
-    T x0, y0, psi0, v0, vt, up0, up1;
+    T x0, y0, psi0, v0, vt, up0, up1, xoff, yoff;
     T rx, ry, rp;  // reference at stage `lane`
     T dt, dtc, Lb, rr_;
     T Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
@@ -61,13 +61,17 @@ template <typename T, int NT> struct Solver {
 
     DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)
     {
-        x0 = z0[4 * (size_t)b]; y0 = z0[4 * (size_t)b + 1]; psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
+        // the NLP is invariant under a translation of (x, y): solve it in vehicle-centred coordinates (recorded paths live hundreds
+        // of metres from their origin; positions would carry ~1e-13 m of rounding = ~1e-12 in the cost, above the Armijo
+        // decrease of the last iterations); predictions are shifted back on output
+        xoff = z0[4 * (size_t)b]; yoff = z0[4 * (size_t)b + 1]; x0 = (T)0; y0 = (T)0;
+        psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
         vt = vtp[b];
         up0 = upp ? upp[2 * (size_t)b] : (T)0; up1 = upp ? upp[2 * (size_t)b + 1] : (T)0;
         rx = ry = rp = (T)0;
         if (lane <= N) {
             const T *r = ref + ((size_t)b * (N + 1) + lane) * 3;
-            rx = r[0]; ry = r[1]; rp = r[2];
+            rx = r[0] - xoff; ry = r[1] - yoff; rp = r[2];
         }
     }
 
@@ -410,7 +414,7 @@ template <typename T, int NT> struct Solver {
     DEV bool interior_point(T (&Uf)[NV])
     {
         const T relax = (T)P.relax;
-        // first guess of the solution inside the bounds (oracle/kmpc_condensed.c::interior_point): accelerations approach
+        // first guess of the solution inside the bounds (same rule as the CPU checker): accelerations approach
         // the reference speed (time constant 1 s), steering the kinematic feed-forward of the reference's mean curvature;
         // reference points 1..N only -- point 0 is a dead input (Q3)
         const T frac = (T)0.6, rr = (T)P.r;
@@ -664,7 +668,7 @@ template <typename T, int NT> struct Solver {
                     mu = fmax(mu, fmin(mucur, rdm / s_d / (T)1e3));  // no barrier target far below the dual infeasibility
                 }
                 const T tau = fmax(tau_min, (T)1 - mu);
-                T ad = 1, Jt = 0;
+                T ad = 1, Jt = 0, alpha_acc = 0;
                 bool accepted = false;
                 for (int pass = 0; pass < 2 && !accepted; ++pass) {
                     if (pass == 1) {  // safeguard: the corrected direction need not be a descent direction -> drop the corrector
@@ -714,18 +718,18 @@ template <typename T, int NT> struct Solver {
 #pragma unroll
                         for (int i = 0; i < NV; ++i) Ut[i] = U[i] + alpha * du[i];
                         Jt = eval(Ut, St);
-                        forms_apply(Ut, au);
                         T lgt = 0;
                         bool ok = true;
 #pragma unroll
                         for (int i = 0; i < NF; ++i)
                             if (fv[i]) {
-                                const T a_ = bu[i] - au[i], b_ = bl[i] + au[i];
+                                // slacks are iterates (as in Ipopt): s -/+ alpha * a_f^T du, never b - a_f^T U (cancellation)
+                                const T a_ = su[i] - alpha * aut[i], b_ = sl[i] + alpha * aut[i];
                                 if (!(a_ > 0) || !(b_ > 0)) ok = false; else lgt += log(a_) + log(b_);
                             }
                         ok = __all(ok);
                         const T phi = sc * Jt - mu * wave_sum(lgt);
-                        if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; break; }
+                        if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; alpha_acc = alpha; break; }
                     }
                 }
                 STAMP(9);
@@ -736,7 +740,7 @@ template <typename T, int NT> struct Solver {
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        su[i] = bu[i] - au[i]; sl[i] = bl[i] + au[i];
+                        su[i] -= alpha_acc * aut[i]; sl[i] += alpha_acc * aut[i];
                         lu[i] += ad * dlu[i]; ll[i] += ad * dll[i];
                         lu[i] = fmax(fmin(lu[i], kappa_sigma * mu / su[i]), mu / (kappa_sigma * su[i]));
                         ll[i] = fmax(fmin(ll[i], kappa_sigma * mu / sl[i]), mu / (kappa_sigma * sl[i]));
@@ -778,7 +782,7 @@ template <typename T, int NT> struct Solver {
         }
         if (io.outX && lane <= N) {
             T *o = io.outX + ((size_t)b * (N + 1) + lane) * 4;
-            o[0] = S.x; o[1] = S.y; o[2] = S.psi; o[3] = S.v;
+            o[0] = S.x + xoff; o[1] = S.y + yoff; o[2] = S.psi; o[3] = S.v;
         }
         STAMP(11);
         STAMP_OUT(io.stamps, b);

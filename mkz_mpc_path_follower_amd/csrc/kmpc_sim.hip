@@ -1,0 +1,56 @@
+// kmpc_sim.hip -- batched vehicle simulator for closed-loop runs, gfx950 only.
+// Restates scripts/vehicle_simulator.py:58-113 for B vehicles at once: one thread per vehicle (the model is a
+// 6-state ODE + 2 actuator lags -- there is nothing to share between lanes), fp64 like the reference, state kept in
+// registers across all sub-steps of a call, so a 0.1 s control period (10 model updates = 100 Euler sub-steps) costs one
+// read and one write of 64 B per vehicle.  FP contraction is off so that every product/sum rounds as in the reference; sin/cos/atan2 come from the device math library (<= 1-2 ulp from numpy's), so parity
+// with the numpy checker is to rounding, not bit-exact (tests/test_closed_loop.py states the tolerance).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+__global__ __launch_bounds__(256) void kmpc_sim_kernel(int B, double *__restrict__ state, const double *__restrict__ cmd, int n_updates)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const double lf = 1.152, lr = 1.693, m = 1840.0, Iz = 3477.0;   // vehicle_simulator.py:61-65
+    const double C_alpha_f = 4.0703e4, C_alpha_r = 6.4495e4;        // :66-67
+    const double deltaT = 0.01 / 10.0;                              // dt_model / disc_steps, :24,:69
+    const double pi = 3.141592653589793;
+    double *s = state + 8 * (size_t)i;
+    double X = s[0], Y = s[1], psi = s[2], vx = s[3], vy = s[4], wz = s[5], acc = s[6], df = s[7];
+    const double acc_des = cmd[2 * (size_t)i], df_des = cmd[2 * (size_t)i + 1];
+    for (int it = 0; it < n_updates * 10; ++it) {
+        double alpha_f = 0.0, alpha_r = 0.0;
+        if (fabs(vx) > 1e-6) {                                      // :75
+            alpha_f = df - atan2(vy + lf * wz, vx);                 // :76
+            alpha_r = -atan2(vy - lf * wz, vx);                     // :77 (lf where lr is expected -- as in the reference)
+        }
+        const double Fyf = C_alpha_f * alpha_f, Fyr = C_alpha_r * alpha_r;  // :80-81
+        const double sd = sin(df), cd = cos(df), sp = sin(psi), cp = cos(psi);
+        const double vx_n = fmax(0.0, vx + deltaT * (acc - 1 / m * Fyf * sd + wz * vy));   // :84
+        double vy_n = 0.0, wz_n = 0.0;
+        if (vx_n > 1e-6) {                                          // :87
+            vy_n = vy + deltaT * (1.0 / m * (Fyf * cd + Fyr) - wz * vx);               // :88
+            wz_n = wz + deltaT * (1.0 / Iz * (lf * Fyf * cd - lr * Fyr));              // :89
+        }
+        const double psi_n = psi + deltaT * wz;                     // :94
+        const double X_n = X + deltaT * (vx * cp - vy * sp);        // :95
+        const double Y_n = Y + deltaT * (vx * sp + vy * cp);        // :96
+        X = X_n; Y = Y_n;
+        const double a = psi_n + pi, p2 = 2.0 * pi;                 // :101  python's float % : result has the divisor's sign
+        double md = fmod(a, p2);
+        if (md < 0.0) md += p2;
+        psi = md - pi;
+        vx = vx_n; vy = vy_n; wz = wz_n;
+        acc = 5.0 * (acc_des - acc) * deltaT + acc;                 // :112
+        df = 5.0 * (df_des - df) * deltaT + df;                     // :113
+    }
+    s[0] = X; s[1] = Y; s[2] = psi; s[3] = vx; s[4] = vy; s[5] = wz; s[6] = acc; s[7] = df;
+}
+
+hipError_t kmpc_launch_sim(int B, double *state, const double *cmd, int n_updates, hipStream_t st)
+{
+    hipLaunchKernelGGL(kmpc_sim_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, state, cmd, n_updates);
+    return hipGetLastError();
+}

@@ -346,10 +346,24 @@ static int interior_point(const kmpc_params *p, const kmpc_problem *q, double re
     return 0;
 }
 
-int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc_opts *o,
+int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const kmpc_opts *o,
                          double *U, double *X, double *lam_out, kmpc_result *res)
 {
     const int N = p->N, n = 2 * N;
+    /* The NLP is invariant under a translation of (x, y): solve it in vehicle-centred coordinates.  Recorded paths live
+       hundreds of metres from their origin; positions then carry ~1e-13 m of rounding, i.e. ~1e-12 in the cost -- more
+       than the Armijo decrease of the last iterations, which then stall at an error of ~1e-6 (closed-loop test). */
+    kmpc_problem q_local = *q_in;
+    double *ref_local = (double *)malloc((size_t)(N + 1) * 3 * sizeof(double));
+    const double x_off = q_in->z0[0], y_off = q_in->z0[1];
+    for (int k = 0; k <= N; ++k) {
+        ref_local[3 * k] = q_in->ref[3 * k] - x_off;
+        ref_local[3 * k + 1] = q_in->ref[3 * k + 1] - y_off;
+        ref_local[3 * k + 2] = q_in->ref[3 * k + 2];
+    }
+    q_local.z0[0] = 0.0; q_local.z0[1] = 0.0;
+    q_local.ref = ref_local;
+    const kmpc_problem *q = &q_local;
     forms_t F = {N, n, 2 * (N - 1), 5 * N - 2, p->dt};
     const int nf = F.nf;
     double *mem = (double *)calloc((size_t)(3 * n * n + 12 * n + 14 * nf + (N + 1) * 8), sizeof(double));
@@ -578,24 +592,25 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q, const kmpc
                 for (int j = 0; j < n; ++j) Ut[j] = U[j] + alpha * du[j];
                 kmpc_rollout(p, q->z0, Ut, Xt);
                 double phi = sc * kmpc_cost(p, q, Ut, Xt);
-                forms_apply(&F, Ut, w2);
                 int ok = 1;
                 for (int f = 0; f < nf; ++f) {
-                    const double a = bu[f] - w2[f], b = bl[f] + w2[f];
+                    /* slacks are iterates (as in Ipopt), advanced by s -/+ alpha * a_f^T du: recomputing b - a_f^T U
+                       would lose 7 digits to cancellation once an active slack is ~1e-9 */
+                    const double a = su[f] - alpha * aut[f], b = sl[f] + alpha * aut[f];
                     if (!(a > 0.0) || !(b > 0.0)) { ok = 0; break; }
                     phi -= mu * (log(a) + log(b));
                 }
                 /* small slack for round-off as in Ipopt (10 * eps * |phi|) */
+                if (getenv("KMPC_TRACE_LS")) fprintf(stderr, "   ls it %d pass %d l %d alpha %.3e ok %d phi-phi0 %.3e  alpha*dphi %.3e  (phi0 %.6e, sc %.3e)\n", it, pass, l, alpha, ok, phi - phi0, alpha * dphi, phi0, sc);
                 if (ok && phi - phi0 - 10.0 * 2.2e-16 * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = 1; break; }
             }
         }
         if (!accepted) { status = err0 <= 100.0 * o->tol ? KMPC_OPTIMAL : KMPC_NUMERICAL_ERROR; break; }  /* acceptable level reached */
-        if (getenv("KMPC_TRACE")) fprintf(stderr, "it %3d J %.10g err0 %.3e mu %.2e ap %.3g ad %.3g alpha %.3g rd %.3e comp %.3e gn %d\n", it, J, err0, mu, ap, ad, alpha, rdmax, cmax0, use_gn);
+        if (getenv("KMPC_TRACE")) fprintf(stderr, "it %3d J %.10g err0 %.3e mu %.2e ap %.3g ad %.3g alpha %.3g rd %.3e comp %.3e gn %d reg/hmax %.2e\n", it, J, err0, mu, ap, ad, alpha, rdmax, cmax0, use_gn, reg / hmax);
         memcpy(U, Ut, (size_t)n * sizeof(double));
-        forms_apply(&F, U, au);
         for (int f = 0; f < nf; ++f) {
-            su[f] = bu[f] - au[f];
-            sl[f] = bl[f] + au[f];
+            su[f] -= alpha * aut[f];
+            sl[f] += alpha * aut[f];
             lu[f] += ad * dlu[f];
             ll[f] += ad * dll[f];
             lu[f] = fmax(fmin(lu[f], kappa_sigma * mu / su[f]), mu / (kappa_sigma * su[f]));
@@ -613,7 +628,11 @@ finish:
     }
     free(Ubest);
     kmpc_rollout(p, q->z0, U, Xl);
-    if (X) memcpy(X, Xl, (size_t)(N + 1) * 4 * sizeof(double));
+    if (X)
+        for (int k = 0; k <= N; ++k) {
+            X[4 * k] = Xl[4 * k] + x_off; X[4 * k + 1] = Xl[4 * k + 1] + y_off;
+            X[4 * k + 2] = Xl[4 * k + 2]; X[4 * k + 3] = Xl[4 * k + 3];
+        }
     if (lam_out) {
         /* kmpc_ineq row order */
         const int R = F.R;
@@ -636,6 +655,7 @@ finish:
         res->mu = mu;
     }
     free(mem);
+    free(ref_local);
     return status;
 }
 
