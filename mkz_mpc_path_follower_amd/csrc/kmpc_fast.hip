@@ -95,7 +95,7 @@ template <typename T, int N> struct FastSolver {
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
     static_assert(n + 1 <= 64 && n % 8 == 0, "fast kernel needs 2N + 1 <= 64 and N % 4 == 0");
     typedef typename Real<T>::acc_t acc_t;
-    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 2 * 64 * NF; }
+    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 64 + 2 * 64 * NF; }
     // start of column j minus j, so that element (row i, col j) lives at offc(j) + i
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
@@ -104,7 +104,7 @@ template <typename T, int N> struct FastSolver {
     const KP &P;
     int lane;  // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the
                // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
-    T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *cub, *clb;
+    T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *gb, *cub, *clb;
     T dinv_l;  // 1 / L[lane][lane] of the current factor
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
     T dt, dtc, Lb, rr_, Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
@@ -119,7 +119,8 @@ template <typename T, int N> struct FastSolver {
         opb = lin + LIN_STRIDE * (N + 1);
         cs = opb + 8 * 64;      // wave-uniform scalars that are read once or twice per iteration live here, not in VGPRs
         ubest = cs + 16;        // last iterate that passed Ipopt's test
-        cub = ubest + 64; clb = cub + 64 * NF;  // corrector terms
+        gb = ubest + 64;        // gradient of the current linearisation (lane j: g_j)
+        cub = gb + 64; clb = cub + 64 * NF;  // corrector terms
         dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
         Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
         Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
@@ -656,7 +657,7 @@ template <typename T, int N> struct FastSolver {
         const T kappa_eps = 10, kappa_mu = (T)0.2, tau_min = (T)0.99, kappa_sigma = (T)1e10, eta_phi = (T)1e-8, s_max = 100;
         const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
         const bool exact = P.hessian == 1;
-        T U, Ut, g = 0, du = 0, rhs = 0;
+        T U, Ut, du = 0;
         // slacks are iterates, advanced by s -/+ alpha * a_f^T du (as in Ipopt): recomputing b - a_f^T U would lose 7 digits to
         // cancellation once an active slack is ~1e-9; corrector terms are parked in LDS (cub/clb)
         T sup[NF], slo[NF], lu[NF], ll[NF], aut[NF], w[NF];
@@ -672,7 +673,6 @@ template <typename T, int N> struct FastSolver {
         bool use_exact = exact;
         enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3, RESTEP = 4 };
         const bool pc = P.mu_strategy == 1;
-        T ya = 0;
         bool corr_active = false, first_attempt = true;
 #pragma unroll
         for (int i = 0; i < NF; ++i) cub[lane + 64 * i] = clb[lane + 64 * i] = (T)0;
@@ -755,7 +755,8 @@ template <typename T, int N> struct FastSolver {
             if (!restep) {
             if (mode != REFACTOR) {
             U = Ut; cs[C_J] = Jt;
-            g = linearize(St, exact);
+            const T g = linearize(St, exact);
+            gb[lane] = g;
             STAMP(1);
                 if (mode == FIRST) {
                     forms_apply(U, w);
@@ -826,7 +827,7 @@ template <typename T, int N> struct FastSolver {
                 STAMP(2);
             }
             // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
-            rhs = -sc * g;
+            const T rhs = -sc * gb[lane];
 #pragma unroll
             for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / sup[i] + ll[i] / slo[i] : (T)0;
             stage_form_weights(w);
@@ -870,13 +871,13 @@ template <typename T, int N> struct FastSolver {
             }
             if (use_exact && reg > (T)0) cs[C_DWL] = reg;
             if (use_exact) cs[C_DWS] = reg;
-            ya = lane < n ? Lc[offc_rt(lane) + n] : (T)0;  // L^{-1}(-sc*g)
+            // L^{-1}(-sc*g) sits in row n of the factor image; re-read where needed rather than held in registers
 #pragma unroll
             for (int i = 0; i < NF; ++i) cub[lane + 64 * i] = clb[lane + 64 * i] = (T)0;
             corr_active = false;
             if (pc) {
                 // Mehrotra predictor: affine-scaling step on the same factor -> this iteration's barrier target
-                const T dua = back_subst(ya);
+                const T dua = back_subst(lane < n ? Lc[offc_rt(lane) + n] : (T)0);
                 forms_apply(dua, aut);
                 T apa = 1, ada = 1, mucur = 0, muaff = 0;
 #pragma unroll
@@ -914,7 +915,7 @@ template <typename T, int N> struct FastSolver {
             // centering (+ corrector) part of the step: du = K^{-1}(-sc*g - A^T((mu - corr)/s_u - (mu - corr)/s_l))
 #pragma unroll
             for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - cub[lane + 64 * i]) / sup[i] - (mu - clb[lane + 64 * i]) / slo[i]) : (T)0;
-            du = back_subst(ya + fwd_subst(forms_applyT(w)));
+            du = back_subst((lane < n ? Lc[offc_rt(lane) + n] : (T)0) + fwd_subst(forms_applyT(w)));
             STAMP(15);
             forms_apply(du, aut);
             const T tau = fmax(tau_min, (T)1 - mu);
@@ -935,7 +936,7 @@ template <typename T, int N> struct FastSolver {
                 }
             ap = dpp_min(ap); cs[C_AD] = dpp_min(ad);
             cs[C_PHI0] = sc * cs[C_J] - mu * dpp_sum(lg);
-            cs[C_DPHI] = dpp_sum((lane < n ? sc * g * du : (T)0) + gw);  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
+            cs[C_DPHI] = dpp_sum((lane < n ? sc * gb[lane] * du : (T)0) + gw);  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
             alpha = ap; ls = 0;
             Ut = U + alpha * du;
             mode = TRIAL;
