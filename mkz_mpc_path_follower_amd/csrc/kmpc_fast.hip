@@ -95,7 +95,7 @@ template <typename T, int N> struct FastSolver {
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
     static_assert(n + 1 <= 64 && n % 8 == 0, "fast kernel needs 2N + 1 <= 64 and N % 4 == 0");
     typedef typename Real<T>::acc_t acc_t;
-    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 64 + 2 * 64 * NF; }
+    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 64 + 2 * 64 * NF + 16 * (n / 4); }
     // start of column j minus j, so that element (row i, col j) lives at offc(j) + i
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
@@ -104,8 +104,7 @@ template <typename T, int N> struct FastSolver {
     const KP &P;
     int lane;  // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the
                // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
-    T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *gb, *cub, *clb;
-    T dinv_l;  // 1 / L[lane][lane] of the current factor
+    T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *gb, *cub, *clb, *sinvb;
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
     T dt, dtc, Lb, rr_, Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
 
@@ -121,6 +120,8 @@ template <typename T, int N> struct FastSolver {
         ubest = cs + 16;        // last iterate that passed Ipopt's test
         gb = ubest + 64;        // gradient of the current linearisation (lane j: g_j)
         cub = gb + 64; clb = cub + 64 * NF;  // corrector terms
+        sinvb = clb + 64 * NF;  // D_j^-1 of the factor's 4x4 diagonal blocks (row-major, 16 per 4-column panel)
+        for (int e = lane; e < 16 * (n / 4); e += 64) sinvb[e] = (T)0;
         dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
         Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
         Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
@@ -498,6 +499,21 @@ template <typename T, int N> struct FastSolver {
             const T e33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33))), r3 = rsqrt_(e33);
             const T dmin = fmin(fmin(d00, e11), fmin(e22, e33)), dmax = fmax(fmax(d00, e11), fmax(e22, e33));
             if (!(dmin > Real<T>::tiny() && dmax < (T)1e300)) return false;  // not positive definite (wave-uniform)
+            // block-LDL^T view of the same factor: K = L~ S L~^T with L~ = L D^-1 (D = blockdiag of the 4x4 diagonal factors, so L~ has
+            // unit diagonal blocks) and S^-1 = D^-T D^-1.  The substitutions then have no dependency inside a block (4 readlanes + 4
+            // FMAs per block step) and the rhs row n comes out as S^-1 L~^-1 rhs.  inv = D_j^-1 (lower triangular):
+            const T i10 = -l10 * r0 * r1;
+            const T i21 = -l21 * r1 * r2, i20 = -fma(l21, i10, l20 * r0) * r2;
+            const T i32 = -l32 * r2 * r3, i31 = -fma(l32, i21, l31 * r1) * r3, i30 = -fma(l32, i20, fma(l31, i10, l30 * r0)) * r3;
+            if (lane == 0) {  // D_j^-1, row-major 4x4 (the strict upper part stays zero from construction)
+                T *sq = sinvb + 16 * jb;
+                sq[0] = r0; sq[4] = i10; sq[5] = r1; sq[8] = i20; sq[9] = i21; sq[10] = r2; sq[12] = i30; sq[13] = i31; sq[14] = i32; sq[15] = r3;
+            }
+            // column kk of inv, for this lane's component of L~
+            const T c0 = kk == 0 ? r0 : (T)0;
+            const T c1 = kk == 0 ? i10 : (kk == 1 ? r1 : (T)0);
+            const T c2 = kk == 0 ? i20 : (kk == 1 ? i21 : (kk == 2 ? r2 : (T)0));
+            const T c3 = kk == 0 ? i30 : (kk == 1 ? i31 : (kk == 2 ? i32 : r3));
             T pf[NTF];
             const int jc = j0 + kk;
             T *colL = Lc + offc_rt(jc < n ? jc : 0);
@@ -510,9 +526,9 @@ template <typename T, int N> struct FastSolver {
                 const T x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, a[t][3]))) * r3;
                 const T xs = kk == 0 ? x0 : (kk == 1 ? x1 : (kk == 2 ? x2 : x3));
                 const bool live = row >= jc && row <= n;
-                pf[t] = live ? xs : (T)0;
+                pf[t] = live ? xs : (T)0;                       // component kk of L (MFMA fragment of the trailing update)
                 T *dst = live ? colL + row : xb + lane;
-                *dst = pf[t];
+                *dst = fma(x3, c3, fma(x2, c2, fma(x1, c1, x0 * c0)));  // component kk of L~ = L D^-1
             }
             if (j0 + 4 < n) {
                 const int tmin = (j0 + 4) >> 4;  // first tile column that still has live entries
@@ -555,44 +571,63 @@ template <typename T, int N> struct FastSolver {
         STAMP(14);
         if (!ok) return false;
         WFENCE();
-        dinv_l = lane < n ? (T)1 / Lc[offc_rt(lane) + lane] : (T)0;  // 1 / L[lane][lane]
         return true;
     }
 
-    // Triangular substitutions on the packed factor (lane j <-> component j).  Columns are pre-scaled by the
-    // owner's 1/L_jj off the critical path, so the dependent chain per step is just v_readlane + FMA.
-    // (A variant blocked by the 4-column panels -- inverse diagonal blocks, 4 readlanes + 14 FMAs per block -- measured
-    // slower: 600 cycles per block against 4 x 105 for these steps.)
-    DEV T fwd_subst(T b)  // solves L y = b
+    // Substitutions on the block-LDL^T factor (lane j <-> component j): K^-1 b = L~^-T S^-1 L~^-1 b.  L~ has unit 4x4 diagonal
+    // blocks, so a block step is 4 v_readlane + 4 FMAs on the lanes below (above) the block -- n/4 dependent steps instead of n.
+    DEV T fwd_subst(T b)  // L~ y = b
     {
-        T wv = b * dinv_l;
-#pragma nounroll
-        for (int blk = 0; blk < n / 8; ++blk) {
-            T cv[8];
+        T wv = lane < n ? b : (T)0;
+        T lr[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = 8 * blk + u;
-                const T v = Lc[offc_rt(j) + lane];  // L[lane][j]
-                cv[u] = (lane > j && lane < n) ? v * dinv_l : (T)0;
-            }
+        for (int k = 0; k < 4; ++k) lr[k] = Lc[offc_rt(k) + lane];  // L~[lane][j0+k]
+#pragma unroll 2
+        for (int jb = 0; jb < n / 4 - 1; ++jb) {
+            const int j0 = 4 * jb;
+            T ln[4];  // next block's coefficients are in flight while this block's chain runs
 #pragma unroll
-            for (int u = 0; u < 8; ++u) wv = fma(-cv[u], readlane_(wv, 8 * blk + u), wv);
+            for (int k = 0; k < 4; ++k) ln[k] = Lc[offc_rt(j0 + 4 + k) + lane];
+            const T t0 = readlane_(wv, j0), t1 = readlane_(wv, j0 + 1), t2 = readlane_(wv, j0 + 2), t3 = readlane_(wv, j0 + 3);
+            const T upd = fma(lr[3], t3, lr[2] * t2) + fma(lr[1], t1, lr[0] * t0);
+            wv = (lane >= j0 + 4 && lane < n) ? wv - upd : wv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lr[k] = ln[k];
         }
         return wv;
     }
-    DEV T back_subst(T y)  // solves L^T x = y
+    DEV T back_subst(T z)  // L~^T x = z
     {
-        const T *pc = Lc + offc_rt(lane < n ? lane : 0);
-        T wv = y * dinv_l;
-#pragma nounroll
-        for (int blk = n / 8 - 1; blk >= 0; --blk) {
-            T cv[8];
+        const T *pc = Lc + offc_rt(lane < n ? lane : 0);  // column `lane` of L~: L~[j0+k][lane] = pc[j0+k]
+        T wv = lane < n ? z : (T)0;
+        T lr[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = 8 * blk + u; const T v = pc[i]; cv[u] = (i > lane && lane < n) ? v * dinv_l : (T)0; }
+        for (int k = 0; k < 4; ++k) lr[k] = pc[n - 4 + k];
+#pragma unroll 2
+        for (int jb = n / 4 - 1; jb >= 1; --jb) {
+            const int j0 = 4 * jb;
+            T ln[4];
 #pragma unroll
-            for (int u = 7; u >= 0; --u) wv = fma(-cv[u], readlane_(wv, 8 * blk + u), wv);
+            for (int k = 0; k < 4; ++k) ln[k] = pc[j0 - 4 + k];
+            const T t0 = readlane_(wv, j0), t1 = readlane_(wv, j0 + 1), t2 = readlane_(wv, j0 + 2), t3 = readlane_(wv, j0 + 3);
+            const T upd = fma(lr[3], t3, lr[2] * t2) + fma(lr[1], t1, lr[0] * t0);
+            wv = lane < j0 ? wv - upd : wv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lr[k] = ln[k];
         }
         return wv;
+    }
+    DEV T diag_solve(T y)  // S^-1 y = D^-T (D^-1 y): every 4x4 block at once, operands of the quad through DPP quad_perm
+    {
+        const int a = lane & 3;
+        const T *blk = sinvb + 16 * ((lane < n ? lane : 0) >> 2);
+        const T *dr = blk + 4 * a;   // row a of D^-1 (zero above the diagonal)
+        const T *dc = blk + a;       // column a of D^-1 (zero above the diagonal): dc[4 m]
+        const T y0 = dpp_mov0<0x00, 0xf>(y), y1 = dpp_mov0<0x55, 0xf>(y), y2 = dpp_mov0<0xaa, 0xf>(y), y3 = dpp_mov0<0xff, 0xf>(y);
+        const T u = fma(dr[3], y3, dr[2] * y2) + fma(dr[1], y1, dr[0] * y0);
+        const T u0 = dpp_mov0<0x00, 0xf>(u), u1 = dpp_mov0<0x55, 0xf>(u), u2 = dpp_mov0<0xaa, 0xf>(u), u3 = dpp_mov0<0xff, 0xf>(u);
+        const T zz = fma(dc[12], u3, dc[8] * u2) + fma(dc[4], u1, dc[0] * u0);
+        return lane < n ? zz : (T)0;
     }
 
     DEV bool interior_point(T &Uf)
@@ -871,7 +906,7 @@ template <typename T, int N> struct FastSolver {
             }
             if (use_exact && reg > (T)0) cs[C_DWL] = reg;
             if (use_exact) cs[C_DWS] = reg;
-            // L^{-1}(-sc*g) sits in row n of the factor image; re-read where needed rather than held in registers
+            // S^-1 L~^-1 (-sc*g) sits in row n of the factor image; re-read where needed rather than held in registers
 #pragma unroll
             for (int i = 0; i < NF; ++i) cub[lane + 64 * i] = clb[lane + 64 * i] = (T)0;
             corr_active = false;
@@ -915,7 +950,7 @@ template <typename T, int N> struct FastSolver {
             // centering (+ corrector) part of the step: du = K^{-1}(-sc*g - A^T((mu - corr)/s_u - (mu - corr)/s_l))
 #pragma unroll
             for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - cub[lane + 64 * i]) / sup[i] - (mu - clb[lane + 64 * i]) / slo[i]) : (T)0;
-            du = back_subst((lane < n ? Lc[offc_rt(lane) + n] : (T)0) + fwd_subst(forms_applyT(w)));
+            du = back_subst((lane < n ? Lc[offc_rt(lane) + n] : (T)0) + diag_solve(fwd_subst(forms_applyT(w))));
             STAMP(15);
             forms_apply(du, aut);
             const T tau = fmax(tau_min, (T)1 - mu);
