@@ -695,10 +695,10 @@ template <typename T, int N> struct FastSolver {
         T U, Ut, du = 0;
         // slacks are iterates, advanced by s -/+ alpha * a_f^T du (as in Ipopt): recomputing b - a_f^T U would lose 7 digits to
         // cancellation once an active slack is ~1e-9; corrector terms are parked in LDS (cub/clb)
-        T sup[NF], slo[NF], lu[NF], ll[NF], aut[NF], w[NF];
+        T sup[NF], slo[NF], isu[NF], isl[NF], lu[NF], ll[NF], aut[NF], w[NF];  // isu/isl = 1/slack, refreshed when the slacks move
         bool fv[NF];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; lu[i] = ll[i] = sup[i] = slo[i] = aut[i] = (T)0; }
+        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; lu[i] = ll[i] = sup[i] = slo[i] = isu[i] = isl[i] = aut[i] = (T)0; }
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
         enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J };
         cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_AD] = 0; cs[C_J] = 0;
@@ -780,10 +780,11 @@ template <typename T, int N> struct FastSolver {
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
                         const T su = sup[i], sl = slo[i];
-                        lu[i] += ad * ((mu - cub[lane + 64 * i] - lu[i] * su) / su + lu[i] / su * aut[i]);
-                        ll[i] += ad * ((mu - clb[lane + 64 * i] - ll[i] * sl) / sl - ll[i] / sl * aut[i]);
+                        lu[i] += ad * ((mu - cub[lane + 64 * i] - lu[i] * su) * isu[i] + lu[i] * isu[i] * aut[i]);
+                        ll[i] += ad * ((mu - clb[lane + 64 * i] - ll[i] * sl) * isl[i] - ll[i] * isl[i] * aut[i]);
                         sup[i] = su - alpha * aut[i];
                         slo[i] = sl + alpha * aut[i];
+                        isu[i] = (T)1 / sup[i]; isl[i] = (T)1 / slo[i];
                     }
             }
             const bool restep = mode == RESTEP;
@@ -800,18 +801,19 @@ template <typename T, int N> struct FastSolver {
                         T bu_, bl_;
                         form_bounds(lane + 64 * i, bu_, bl_);
                         sup[i] = bu_ - w[i]; slo[i] = bl_ + w[i];
+                        isu[i] = fv[i] ? (T)1 / sup[i] : (T)0; isl[i] = fv[i] ? (T)1 / slo[i] : (T)0;
                     }
                     const T gm = dpp_max(fabs(g));
                     sc = gm > (T)100 ? (T)100 / gm : (T)1;  // Ipopt nlp_scaling_max_gradient
 #pragma unroll
-                    for (int i = 0; i < NF; ++i) { lu[i] = fv[i] ? mu / sup[i] : (T)0; ll[i] = fv[i] ? mu / slo[i] : (T)0; }
+                    for (int i = 0; i < NF; ++i) { lu[i] = mu * isu[i]; ll[i] = mu * isl[i]; }
                 } else {
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
                         if (fv[i]) {
                             const T su = sup[i], sl = slo[i];
-                            lu[i] = fmax(fmin(lu[i], kappa_sigma * mu / su), mu / (kappa_sigma * su));
-                            ll[i] = fmax(fmin(ll[i], kappa_sigma * mu / sl), mu / (kappa_sigma * sl));
+                            lu[i] = fmax(fmin(lu[i], kappa_sigma * mu * isu[i]), mu * isu[i] / kappa_sigma);
+                            ll[i] = fmax(fmin(ll[i], kappa_sigma * mu * isl[i]), mu * isl[i] / kappa_sigma);
                         }
                 }
                 if (iters >= P.max_iter) { mode = FINAL; Ut = U; continue; }  // status stays ITERATION_LIMIT
@@ -864,7 +866,7 @@ template <typename T, int N> struct FastSolver {
             // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
             const T rhs = -sc * gb[lane];
 #pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / sup[i] + ll[i] / slo[i] : (T)0;
+            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] * isu[i] + ll[i] * isl[i] : (T)0;
             stage_form_weights(w);
             STAMP(6);
             bool factored;
@@ -914,24 +916,22 @@ template <typename T, int N> struct FastSolver {
                 // Mehrotra predictor: affine-scaling step on the same factor -> this iteration's barrier target
                 const T dua = back_subst(lane < n ? Lc[offc_rt(lane) + n] : (T)0);
                 forms_apply(dua, aut);
-                T apa = 1, ada = 1, mucur = 0, muaff = 0;
+                // step lengths to the boundary as reciprocals: 1/alpha = max(1, max_f(-ds/s)); for the affine step -dlam/lam = 1 + ds/s
+                T rpa = 1, rda = 1, mucur = 0, muaff = 0;
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
-                        const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
-                        const T dlu = -lu[i] - lu[i] / su * dsu, dll = -ll[i] - ll[i] / sl * dsl;
-                        if (dsu < 0) apa = fmin(apa, -su / dsu);
-                        if (dsl < 0) apa = fmin(apa, -sl / dsl);
-                        if (dlu < 0) ada = fmin(ada, -lu[i] / dlu);
-                        if (dll < 0) ada = fmin(ada, -ll[i] / dll);
-                        mucur += su * lu[i] + sl * ll[i];
+                        const T qu = aut[i] * isu[i], ql = aut[i] * isl[i];  // -ds_u/s_u, ds_l/s_l
+                        rpa = fmax(rpa, fmax(qu, -ql));
+                        rda = fmax(rda, fmax((T)1 - qu, (T)1 + ql));
+                        mucur += sup[i] * lu[i] + slo[i] * ll[i];
                     }
-                apa = dpp_min(apa); ada = dpp_min(ada);
+                const T apa = (T)1 / dpp_max(rpa), ada = (T)1 / dpp_max(rda);
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
                         const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
-                        const T dlu = -lu[i] - lu[i] / su * dsu, dll = -ll[i] - ll[i] / sl * dsl;
+                        const T dlu = -lu[i] - lu[i] * isu[i] * dsu, dll = -ll[i] - ll[i] * isl[i] * dsl;
                         muaff += (su + apa * dsu) * (lu[i] + ada * dlu) + (sl + apa * dsl) * (ll[i] + ada * dll);
                         cub[lane + 64 * i] = dsu * dlu; clb[lane + 64 * i] = dsl * dll;
                     }
@@ -949,27 +949,26 @@ template <typename T, int N> struct FastSolver {
             }
             // centering (+ corrector) part of the step: du = K^{-1}(-sc*g - A^T((mu - corr)/s_u - (mu - corr)/s_l))
 #pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - cub[lane + 64 * i]) / sup[i] - (mu - clb[lane + 64 * i]) / slo[i]) : (T)0;
+            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - cub[lane + 64 * i]) * isu[i] - (mu - clb[lane + 64 * i]) * isl[i]) : (T)0;
             du = back_subst((lane < n ? Lc[offc_rt(lane) + n] : (T)0) + diag_solve(fwd_subst(forms_applyT(w))));
             STAMP(15);
             forms_apply(du, aut);
             const T tau = fmax(tau_min, (T)1 - mu);
-            T ap = 1, lg = 0, gw = 0;
-            T ad = 1;
+            T rp = 0, rq = 0, lg = 0, gw = 0;
 #pragma unroll
             for (int i = 0; i < NF; ++i)
                 if (fv[i]) {
                     const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
-                    const T dlu = (mu - cub[lane + 64 * i] - lu[i] * su) / su - lu[i] / su * dsu;
-                    const T dll = (mu - clb[lane + 64 * i] - ll[i] * sl) / sl - ll[i] / sl * dsl;
-                    gw += (mu / su - mu / sl) * aut[i];
-                    if (dsu < 0) ap = fmin(ap, -tau * su / dsu);
-                    if (dsl < 0) ap = fmin(ap, -tau * sl / dsl);
-                    if (dlu < 0) ad = fmin(ad, -tau * lu[i] / dlu);
-                    if (dll < 0) ad = fmin(ad, -tau * ll[i] / dll);
+                    const T dlu = (mu - cub[lane + 64 * i] - lu[i] * su) * isu[i] - lu[i] * isu[i] * dsu;
+                    const T dll = (mu - clb[lane + 64 * i] - ll[i] * sl) * isl[i] - ll[i] * isl[i] * dsl;
+                    gw += mu * (isu[i] - isl[i]) * aut[i];
+                    rp = fmax(rp, fmax(-dsu * isu[i], -dsl * isl[i]));
+                    rq = fmax(rq, fmax(-dlu / lu[i], -dll / ll[i]));
                     lg += log(su * sl);
                 }
-            ap = dpp_min(ap); cs[C_AD] = dpp_min(ad);
+            // fraction to the boundary: alpha = min(1, tau * min(-s/ds)) = tau / max(tau, max(-ds/s))
+            const T ap = tau / fmax(tau, dpp_max(rp));
+            cs[C_AD] = tau / fmax(tau, dpp_max(rq));
             cs[C_PHI0] = sc * cs[C_J] - mu * dpp_sum(lg);
             cs[C_DPHI] = dpp_sum((lane < n ? sc * gb[lane] * du : (T)0) + gw);  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
             alpha = ap; ls = 0;
