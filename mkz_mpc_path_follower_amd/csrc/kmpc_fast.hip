@@ -343,67 +343,80 @@ template <typename T, int N> struct FastSolver {
         r.a02 = q[0]; r.a03 = q[1]; r.a12 = q[2]; r.a13 = q[3]; r.a23 = q[4]; r.bx = q[5]; r.by = q[6]; r.bp = q[7];
         r.mpp = exs * q[8]; r.mpv = exs * q[9]; r.mpd = exs * q[10]; r.mvd = exs * q[11]; r.mdd = exs * q[12];
     }
-    DEV void condense(bool exact, T sc, acc_t (&acc)[NTT])
+    struct CondState { T gx, gy, gp, gv, fa[NT], fb[NT]; Rec cur; };
+    // Trips [s0, s1) of the stage loop with a FIXED number of live tile rows (ROWS = tile rows that hold columns < 2s), so the body
+    // is one basic block: the products of state s are issued first and run on the matrix cores in the shadow of the recursion work.
+    template <int ROWS> DEV void condense_trips(int s0, int s1, CondState &S, acc_t (&acc)[NTT], T sc, T exs)
     {
         const int kk = lane >> 4, c = lane & 15;
-#pragma unroll
-        for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
-        T gx = 0, gy = 0, gp = 0, gv = 0;            // column `lane` of G at the current state
         const T pef = (lane & 1) ? (T)1 : (T)0;      // d_f columns take B's steering column, acc columns (0,0,0,dt)
         const T gvnew = (lane & 1) ? (T)0 : dt;
         T *colK = Lc + offc_rt(lane < n ? lane : 0);  // column `lane` of the packed K image
-        const T exs = exact ? (T)1 : (T)0;
-        T fa[NT], fb[NT];                            // MFMA fragments of the state whose products are still to be issued
-#pragma unroll
-        for (int t = 0; t < NT; ++t) fa[t] = fb[t] = (T)0;
-        // stage records are fetched one trip ahead: no LDS round trip on the recursion's path
-        Rec cur;
-        load_rec(cur, 0, exs);
 #pragma nounroll
-        for (int s = 0; s < N; ++s) {
+        for (int s = s0; s < s1; ++s) {
             Rec nxt;
-            load_rec(nxt, s + 1, exs);
+            load_rec(nxt, s + 1, exs);  // stage records are fetched one trip ahead: no LDS round trip on the recursion's path
+            // products of state s (fragments fetched one trip ago)
+#pragma unroll
+            for (int ti = 0; ti < ROWS; ++ti)
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj)
+                    acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(S.fa[ti], S.fb[tj], acc[ti * (ti + 1) / 2 + tj]);
             // odd row rho = 2s+1 of the image from G_s (zero second-order part when !exact)
             const int rho = 2 * s + 1;
-            const T val = sc * (cur.mpd * gp + cur.mvd * gv) + (lane == rho ? sc * cur.mdd : (T)0);
+            const T val = sc * (S.cur.mpd * S.gp + S.cur.mvd * S.gv) + (lane == rho ? sc * S.cur.mdd : (T)0);
             T *dst = (lane <= rho && lane < n) ? colK + rho : xb + lane;
             *dst = val;
             // ---- advance the recursion to state s+1 ---------------------------------------------------------------
-            gx += cur.a02 * gp + cur.a03 * gv;
-            gy += cur.a12 * gp + cur.a13 * gv;
-            gp += cur.a23 * gv;
-            const bool isnew = (lane >> 1) == s;   // columns 2s, 2s+1 enter with B_s
-            gx = isnew ? cur.bx * pef : gx;
-            gy = isnew ? cur.by * pef : gy;
-            gp = isnew ? cur.bp * pef : gp;
-            gv = isnew ? gvnew : gv;
+            S.gx += S.cur.a02 * S.gp + S.cur.a03 * S.gv;
+            S.gy += S.cur.a12 * S.gp + S.cur.a13 * S.gv;
+            S.gp += S.cur.a23 * S.gv;
+            // columns 2s, 2s+1 enter with B_s; their G was exactly zero until now, so entering is an FMA with an indicator
+            const bool isnew = (lane >> 1) == s;
+            const T ind = isnew ? pef : (T)0;
+            S.gx = fma(ind, S.cur.bx, S.gx);
+            S.gy = fma(ind, S.cur.by, S.gy);
+            S.gp = fma(ind, S.cur.bp, S.gp);
+            S.gv += isnew ? gvnew : (T)0;
             // weights of state s+1: 2Q_{s+1} + M_{s+1}^{psi,v}
             const T Cv1 = s + 1 <= N - 1 ? (T)2 * Cv : (T)0;
             // component-major staging: opb[comp][col]
-            opb[0 * 64 + lane] = gx; opb[1 * 64 + lane] = gy; opb[2 * 64 + lane] = gp; opb[3 * 64 + lane] = gv;
-            opb[4 * 64 + lane] = (T)2 * Cx * gx;
-            opb[5 * 64 + lane] = (T)2 * Cy * gy;
-            opb[6 * 64 + lane] = ((T)2 * Cp + nxt.mpp) * gp + nxt.mpv * gv;
-            opb[7 * 64 + lane] = Cv1 * gv + nxt.mpv * gp;
+            opb[0 * 64 + lane] = S.gx; opb[1 * 64 + lane] = S.gy; opb[2 * 64 + lane] = S.gp; opb[3 * 64 + lane] = S.gv;
+            opb[4 * 64 + lane] = (T)2 * Cx * S.gx;
+            opb[5 * 64 + lane] = (T)2 * Cy * S.gy;
+            opb[6 * 64 + lane] = ((T)2 * Cp + nxt.mpp) * S.gp + nxt.mpv * S.gv;
+            opb[7 * 64 + lane] = Cv1 * S.gv + nxt.mpv * S.gp;
             WFENCE();
-            // products of state s (fragments fetched one trip ago) go to the matrix cores; then the same registers take the
-            // fragments of state s+1, whose LDS latency is covered by the next trip's recursion work
+            // the record fetched at the top of this trip is long complete: take its (free) wait HERE, before the fragment reads are
+            // issued -- otherwise the in-order LDS counter makes the next trip's first use of the record wait for the fragments too
+            pin(nxt.a02); pin(nxt.a03); pin(nxt.a12); pin(nxt.a13); pin(nxt.a23); pin(nxt.bx); pin(nxt.by); pin(nxt.bp);
+            pin(nxt.mpp); pin(nxt.mpv); pin(nxt.mpd); pin(nxt.mvd); pin(nxt.mdd);
+            // fragments of state s+1 (the registers were consumed by the MFMAs at the top)
 #pragma unroll
-            for (int ti = 0; ti < NT; ++ti)
-                if (16 * ti < 2 * s) {
-#pragma unroll
-                    for (int tj = 0; tj <= ti; ++tj)
-                        acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc[ti * (ti + 1) / 2 + tj]);
-                }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { fa[t] = opb[kk * 64 + 16 * t + c]; fb[t] = opb[(4 + kk) * 64 + 16 * t + c]; }
-            cur = nxt;
+            for (int t = 0; t < NT; ++t) { S.fa[t] = opb[kk * 64 + 16 * t + c]; S.fb[t] = opb[(4 + kk) * 64 + 16 * t + c]; }
+            S.cur = nxt;
         }
+    }
+    DEV void condense(bool exact, T sc, acc_t (&acc)[NTT])
+    {
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        const T exs = exact ? (T)1 : (T)0;
+        CondState S;
+        S.gx = S.gy = S.gp = S.gv = (T)0;            // column `lane` of G at the current state
+#pragma unroll
+        for (int t = 0; t < NT; ++t) S.fa[t] = S.fb[t] = (T)0;  // MFMA fragments of the state whose products are still to be issued
+        load_rec(S.cur, 0, exs);
+        // trip s multiplies state s, whose columns 0..2s-1 live in ceil(2s/16) tile rows
+        condense_trips<0>(0, 1, S, acc, sc, exs);
+        condense_trips<1>(1, N < 9 ? N : 9, S, acc, sc, exs);
+        if (NT >= 2 && N > 9) condense_trips<(NT >= 2 ? 2 : 1)>(9, N < 17 ? N : 17, S, acc, sc, exs);
+        if (NT >= 3 && N > 17) condense_trips<(NT >= 3 ? 3 : 1)>(17, N, S, acc, sc, exs);
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
             for (int tj = 0; tj <= ti; ++tj)
-                acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc[ti * (ti + 1) / 2 + tj]);
+                acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(S.fa[ti], S.fb[tj], acc[ti * (ti + 1) / 2 + tj]);
     }
 
     // packed KKT image: lower triangle of sc*(H + input Hessian) + A^T W A + reg*I, and the rhs as row n.
