@@ -49,6 +49,30 @@ def measured_traffic_bytes():
         return None
 
 
+def closed_loop_latency(device, steps=150):
+    """SURVEY.md 8(d) config 1 continued: the reference's own horizon (N = 8) in a 10 Hz receding-horizon loop against the
+    simulated plant on the recorded path (tests/golden/path1_decimated.npz), warm-started, one vehicle: per-solve latency."""
+    from mkz_mpc_path_follower_amd.ref_traj import GPSRefTrajectory
+    from mkz_mpc_path_follower_amd.vehicle_sim import VehicleSimulator
+    from mkz_mpc_path_follower_amd.closed_loop import ClosedLoop
+    f = os.path.join(ROOT, "tests", "golden", "path1_decimated.npz")
+    if not os.path.exists(f):
+        return None
+    d = np.load(f)
+    grt = GPSRefTrajectory(arrays=dict(t=d["t"], lat=d["lat"], lon=d["lon"], psi=d["psi"]), traj_horizon=8, traj_dt=0.2, device=device)
+    tr = grt.get_global_trajectory_reference()
+    sim = VehicleSimulator(1, X0=tr[0, 4], Y0=tr[0, 5], Psi0=tr[0, 3], device=device)
+    loop = ClosedLoop(grt, sim, N=8, target_vel=8.0)
+    lat, its, worst = [], [], 0
+    for k in range(steps):
+        o = loop.step(time_solve=True)
+        lat.append(o["solve_s"]); its.append(int(o["iters"][0].item())); worst = max(worst, int(o["status"][0].item()))
+    w = np.array(lat[10:]) * 1e6
+    return {"workload": "N=8, B=1, warm start, 10 Hz closed loop on path1 at 8 m/s, %d steps" % steps, "p50_latency_us": float(np.percentile(w, 50)),
+            "p99_latency_us": float(np.percentile(w, 99)), "first_solve_us": float(lat[0] * 1e6), "mean_iterations": float(np.mean(its[10:])),
+            "worst_status": worst}
+
+
 def cpu_baseline(N, d, budget_s=15.0):
     """oracle/ CPU port (same algorithm, scalar C, pthreads over problems) on a bounded sample."""
     from oracle import oracle as O
@@ -169,6 +193,7 @@ def main():
                 torch.cuda.synchronize()
                 lat.append(time.perf_counter() - t)
             res["p50_latency_us_B1"] = float(np.percentile(lat[10:], 50) * 1e6)
+            res["closed_loop_N8"] = closed_loop_latency(local)
             if not a.no_cpu_baseline:
                 cb, ro = cpu_baseline(N, d)
                 res["cpu_baseline"] = cb

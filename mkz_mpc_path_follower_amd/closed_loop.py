@@ -32,13 +32,22 @@ class ClosedLoop:
         self.out = None
         self.k = 0
 
-    def step(self, plant_updates=10):
+    def step(self, plant_updates=10, time_solve=False):
+        """time_solve=True brackets the solve with device synchronisations and returns its wall time (`solve_s`)"""
+        import time
         st = self.sim.state
         pose = st[:, 0:3].contiguous()
         ref, stop = self.grt.get_waypoints_batch(pose, None if self.track_with_time else self.v_target)
         self.command_stop |= stop.bool()                                            # :100-103
         z0 = st[:, 0:4].contiguous()                                                # x, y, psi, v = vx  (state_est, :43-46 of the simulator)
+        if time_solve:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         self.out = self.mpc.solve(z0, ref, self.v_target, self.u_prev, warm_U=self.warm_U, warm=self.have_warm, out=self.out)
+        solve_s = None
+        if time_solve:
+            torch.cuda.synchronize()
+            solve_s = time.perf_counter() - t0
         self.have_warm = True
         u0 = self.out["u0"]
         stopc = self.command_stop.unsqueeze(1)
@@ -48,4 +57,4 @@ class ClosedLoop:
         self.sim.cmd.copy_(cmd)
         self.sim._update_vehicle_model(plant_updates)
         self.k += 1
-        return dict(ref=ref, cmd=cmd, status=self.out["status"], iters=self.out["iters"], cost=self.out["cost"])
+        return dict(ref=ref, cmd=cmd, status=self.out["status"], iters=self.out["iters"], cost=self.out["cost"], solve_s=solve_s)

@@ -117,3 +117,85 @@ def test_all_gather_of_solution_shards_gloo_world2(B):
     for p in ps:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_ros_adapter_topic_surface():
+    """the rospy adapter reproduces mpc_cmd_pub.jl's node name, topics, queue sizes, 10 Hz rate, the one-shot
+    `enable`, the rosparam checks and the stop latch -- checked against a stub rospy (ROS is not installed here) and a stub solver."""
+    import types
+    from mkz_mpc_path_follower_amd import ros_node
+
+    log = {"pubs": {}, "subs": {}, "published": [], "rate": None, "node": None, "sleeps": 0}
+
+    class Pub:
+        def __init__(self, topic, cls, queue_size=None):
+            log["pubs"][topic] = (cls.__name__, queue_size); self.topic = topic
+        def publish(self, m):
+            log["published"].append((self.topic, m))
+
+    class Rate:
+        def __init__(self, hz): log["rate"] = hz
+        def sleep(self): log["sleeps"] += 1
+
+    def mk(name, **fields):
+        def init(self):
+            self.header = types.SimpleNamespace(stamp=None)
+            for k, v in fields.items():
+                setattr(self, k, v)
+        return type(name, (), {"__init__": init})
+
+    params = {"mat_waypoints": "x.mat", "track_using_time": False, "target_vel": 5.0}
+    state = {"cb": None}
+
+    def Subscriber(topic, cls, cb, queue_size=None):
+        log["subs"][topic] = (cls.__name__, queue_size); state["cb"] = cb
+
+    rospy = types.SimpleNamespace(has_param=lambda k: k in params, get_param=lambda k, d=None: params.get(k, d),
+                                  init_node=lambda n: log.__setitem__("node", n), Publisher=Pub, Subscriber=Subscriber, Rate=Rate,
+                                  is_shutdown=lambda: False, get_rostime=lambda: 123.0)
+    msgs = types.SimpleNamespace(MPC_cmd=mk("MPC_cmd", accel_cmd=0.0, steer_angle_cmd=0.0), mpc_path=mk("mpc_path", xs=[], ys=[], psis=[]),
+                                 state_est=mk("state_est", x=0.0, y=0.0, psi=0.0, v=0.0))
+    std_msgs = types.SimpleNamespace(Empty=mk("Empty"))
+
+    class FakeMPC:  # the six module functions, recording the call order
+        def __init__(self): self.calls = []
+        def update_cost(self, *w): self.calls.append(("cost", w))
+        def update_init_cond(self, *a): self.calls.append(("init", a))
+        def update_reference(self, *a): self.calls.append(("ref", a[3]))
+        def update_current_input(self, d, a): self.calls.append(("input", (d, a)))
+        def solve_model(self): self.calls.append(("solve",)); return 0.3, -0.02, "Optimal"
+        def get_solver_results(self): return ([0.0] * 9,) * 9
+
+    stop_after = {"n": 0}
+
+    class FakeGRT:
+        def get_waypoints(self, x, y, psi, v=None):
+            stop_after["n"] += 1
+            return [0.0] * 9, [0.0] * 9, [0.0] * 9, stop_after["n"] >= 3
+
+    # missing rosparam -> the reference's error text
+    bad = types.SimpleNamespace(**{**rospy.__dict__, "has_param": lambda k: False})
+    with pytest.raises(RuntimeError, match="No Matfile of waypoints provided!"):
+        ros_node.start_mpc_node(rospy=bad, msgs=msgs, std_msgs=std_msgs, grt=FakeGRT(), mpc=FakeMPC(), max_steps=1)
+
+    mpc = FakeMPC()
+    # no state received yet: the loop idles (mpc_cmd_pub.jl:89)
+    node = ros_node.start_mpc_node(rospy=rospy, msgs=msgs, std_msgs=std_msgs, grt=FakeGRT(), mpc=mpc, max_steps=2)
+    assert log["node"] == "dbw_mpc_pf" and log["rate"] == 10.0 and log["sleeps"] == 2
+    assert log["pubs"] == {"mpc_cmd": ("MPC_cmd", 2), "enable": ("Empty", 2), "target_path": ("mpc_path", 2), "mpc_path": ("mpc_path", 2)}
+    assert log["subs"] == {"state_est": ("state_est", 2)}
+    assert [t for t, _ in log["published"]] == ["enable"]
+    assert mpc.calls[0] == ("cost", (9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0))
+    # feed a state and run 3 more passes: 2 solves, then the stop latch
+    m = msgs.state_est(); m.x, m.y, m.psi, m.v = 1.0, 2.0, 0.1, 4.0
+    state["cb"](m)
+    log["published"].clear()
+    for _ in range(3):
+        node.step()
+    topics = [t for t, _ in log["published"]]
+    assert topics == ["mpc_cmd", "target_path", "mpc_path"] * 2 + ["mpc_cmd"]
+    first, last = log["published"][0][1], log["published"][-1][1]
+    assert (first.accel_cmd, first.steer_angle_cmd) == (0.3, -0.02) and first.header.stamp == 123.0
+    assert (last.accel_cmd, last.steer_angle_cmd) == (-1.0, 0.0)
+    assert ("input", (-0.02, 0.3)) in mpc.calls   # steer first (Q6)
+    assert [c[0] for c in mpc.calls].count("solve") == 2
