@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KMPC_ABI_VERSION 3
+#define KMPC_ABI_VERSION 4
 
 /* per-problem status, replaces the Symbol returned by solve_model() (MKZMPCPathFollower.jl:176,182) */
 enum {
@@ -79,6 +79,9 @@ typedef struct kmpc_config {
                                predicted first (key = |v0 - reference speed| + 1.33 * total heading change of the reference), which
                                shortens the tail of a launch whose time is set by its slowest problems.  Results do not depend on it.
                                Calls on one handle must be stream-ordered (the permutation workspace belongs to the handle). */
+    int32_t model;          /* 0 (default) = MKZMPCPathFollower.jl, Cartesian states (x, y, psi, v); 1 = MKZMPCPathFollowerFrenet.jl,
+                               Frenet-frame states (s, e_y, e_psi, v) with a cubic curvature polynomial (kmpc_solve_batch_frenet;
+                               Gauss-Newton Hessian, horizons N <= 24).  kmpc_create picks the cost defaults of the chosen module. */
 } kmpc_config;
 
 typedef struct kmpc_handle kmpc_handle;
@@ -119,6 +122,16 @@ int32_t kmpc_solve_batch(kmpc_handle *h, int32_t B, const void *z0, const void *
                          const void *v_target, const void *u_prev, void *warm_U, int32_t warm,
                          void *out_u0, int32_t *out_status, void *out_cost, void *out_viol,
                          int32_t *out_iters, void *out_U, void *out_X, void *stream);
+
+/* The hot path of the Frenet-frame variant (handle created with cfg.model = 1).  Replaces, for B problems,
+ *   update_init_cond(s, ey, epsi, vel)      (MKZMPCPathFollowerFrenet.jl:132-138) -> z0      [B,4]  s0, ey0, epsi0, v0
+ *   update_reference(path, k_coeffs, v_des) (:142-147)                            -> k_poly  [B,4]  K(s) coefficients, highest
+ *                                                                                    degree first (:38-39); v_target [B]
+ *   update_current_input / solve_model / get_solver_results as in kmpc_solve_batch; out_X [B,N+1,4] = s, ey, epsi, v.
+ * Cost weights: kmpc_set_cost with (0, C_ey, C_epsi, C_ev, C_dacc, C_ddf, C_acc, C_df) -- update_cost (:158-169) has no x slot. */
+int32_t kmpc_solve_batch_frenet(kmpc_handle *h, int32_t B, const void *z0, const void *k_poly, const void *v_target,
+                                const void *u_prev, void *warm_U, int32_t warm, void *out_u0, int32_t *out_status,
+                                void *out_cost, void *out_viol, int32_t *out_iters, void *out_U, void *out_X, void *stream);
 
 /* Same with HOST pointers: copies in, solves, copies out, synchronises.  This is the form the
  * reference's single-problem API (B = 1) maps onto. */

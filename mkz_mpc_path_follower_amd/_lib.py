@@ -22,14 +22,14 @@ class Config(C.Structure):
                 ("max_iter", C.c_int32), ("hessian", C.c_int32), ("tol", C.c_double),
                 ("mu_init", C.c_double), ("bound_relax", C.c_double), ("warm_push", C.c_double),
                 ("warm_mu", C.c_double), ("max_ls", C.c_int32), ("kernel_variant", C.c_int32),
-                ("mu_strategy", C.c_int32), ("indef_strategy", C.c_int32), ("schedule", C.c_int32)]
+                ("mu_strategy", C.c_int32), ("indef_strategy", C.c_int32), ("schedule", C.c_int32), ("model", C.c_int32)]
 
 
 EXPORTS = ["kmpc_abi_version", "kmpc_config_default", "kmpc_create", "kmpc_destroy", "kmpc_set_cost",
            "kmpc_get_cost", "kmpc_solve_batch", "kmpc_solve_batch_host", "kmpc_last_error",
            "kmpc_debug_condense", "kmpc_debug_mfma_probe",
            "kmpc_path_create", "kmpc_path_destroy", "kmpc_waypoints_batch", "kmpc_path_last_error",
-           "kmpc_sim_advance_batch"]
+           "kmpc_sim_advance_batch", "kmpc_solve_batch_frenet"]
 
 _lib = None
 
@@ -53,6 +53,7 @@ def load():
     sig = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.kmpc_solve_batch.argtypes = sig + [vp]
     L.kmpc_solve_batch_host.argtypes = sig
+    L.kmpc_solve_batch_frenet.argtypes = sig + [vp]
     L.kmpc_last_error.argtypes = [vp]
     L.kmpc_last_error.restype = C.c_char_p
     L.kmpc_debug_condense.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]

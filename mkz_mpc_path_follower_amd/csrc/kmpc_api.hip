@@ -17,6 +17,7 @@ template <typename T> hipError_t kmpc_launch_condense(const KP &, const KDbg<T> 
 template <typename T> hipError_t kmpc_launch_probe(const T *, const T *, T *, hipStream_t);
 template <typename T> bool kmpc_fast_available(int N);
 template <typename T> hipError_t kmpc_launch_solve_fast(const KP &, const KIO<T> &, hipStream_t);
+template <typename T> hipError_t kmpc_launch_solve_frenet(const KP &, const KIO<T> &, hipStream_t);
 hipError_t kmpc_launch_sim(int, double *, const double *, int, hipStream_t);
 template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, const T *, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
 
@@ -88,6 +89,7 @@ extern "C" int32_t kmpc_config_default(kmpc_config *c, int32_t N, int32_t dtype)
     c->max_ls = 30;
     c->indef_strategy = N <= 24 ? 2 : 1;  // indefinite exact Hessian: hybrid (GN fallback, then delta_w shift) for short horizons, shift for long ones
     c->schedule = 1;  // longest-predicted-first start order (kmpc_schedule.hip)
+    c->model = 0;
     c->mu_strategy = N <= 24 ? 1 : 0;  // Mehrotra is validated for short horizons; longer ones keep Ipopt's monotone default
     return KMPC_OK;
 }
@@ -101,7 +103,7 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
         !(cfg->v_max > cfg->v_min) || !(cfg->a_max > 0) || !(cfg->steer_max > 0) || !(cfg->steer_max < 1.5) ||
         !(cfg->a_dmax > 0) || !(cfg->steer_dmax > 0) || cfg->max_iter < 1 || cfg->max_ls < 1 || !(cfg->tol > 0) ||
         cfg->kernel_variant < 0 || cfg->kernel_variant > 1 || cfg->mu_strategy < 0 || cfg->mu_strategy > 1 ||
-        cfg->indef_strategy < 0 || cfg->indef_strategy > 2 || cfg->schedule < 0 || cfg->schedule > 1)
+        cfg->indef_strategy < 0 || cfg->indef_strategy > 2 || cfg->schedule < 0 || cfg->schedule > 1 || cfg->model < 0 || cfg->model > 1 || (cfg->model == 1 && cfg->N > 24))
         return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: invalid model / solver parameter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_create: no HIP device");
@@ -116,8 +118,9 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
     h->dbuf = nullptr;
     h->dbuf_bytes = 0;
     h->perm = nullptr; h->tag = nullptr; h->hist = nullptr; h->sched_cap = 0; h->sched_parity = 0;
-    const double w0[8] = {9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0};  // :51-59
-    memcpy(h->cost, w0, sizeof w0);
+    const double w0[8] = {9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0};  // MKZMPCPathFollower.jl:51-59
+    const double w1[8] = {0.0, 9.0, 10.0, 0.5, 100.0, 1000.0, 0.0, 0.0};  // MKZMPCPathFollowerFrenet.jl:51-59 (no x slot)
+    memcpy(h->cost, cfg->model == 1 ? w1 : w0, sizeof w0);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(nullptr, KMPC_ERR_HIP, "kmpc_create: cannot create stream on device %d", device);
@@ -188,6 +191,10 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
     const KP P = make_kp(h, B, warm && warmU ? 1 : 0, -1);
     io.perm = nullptr;
     // start order: only matters once a launch no longer fits on the chip at once (2 waves x 4 SIMDs x 256 CUs)
+    if (h->cfg.model == 1) {  // Frenet functor: `ref` carries k_poly [B,4]; generic kernel, index order
+        HIPCHK(h, kmpc_launch_solve_frenet<T>(P, io, st));
+        return KMPC_OK;
+    }
     if (h->cfg.schedule == 1 && B > 2048) {
         if ((size_t)B > h->sched_cap) {
             if (h->perm) (void)hipFree(h->perm);
@@ -223,12 +230,33 @@ extern "C" int32_t kmpc_solve_batch(kmpc_handle *h, int32_t B, const void *z0, c
     if (B == 0) return KMPC_OK;
     if (!z0 || !ref || !v_target || !u_prev || !out_u0 || !out_status)
         return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch: null required buffer");
+    if (h->cfg.model != 0) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch: handle was created for the Frenet model; use kmpc_solve_batch_frenet");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream, as in HIP
     if (h->cfg.dtype == KMPC_F64)
         return solve_dev<double>(h, B, z0, ref, v_target, u_prev, warm_U, warm, out_u0, out_status, out_cost, out_viol,
                                  out_iters, out_U, out_X, st);
     return solve_dev<float>(h, B, z0, ref, v_target, u_prev, warm_U, warm, out_u0, out_status, out_cost, out_viol,
+                            out_iters, out_U, out_X, st);
+}
+
+extern "C" int32_t kmpc_solve_batch_frenet(kmpc_handle *h, int32_t B, const void *z0, const void *k_poly, const void *v_target,
+                                           const void *u_prev, void *warm_U, int32_t warm, void *out_u0, int32_t *out_status,
+                                           void *out_cost, void *out_viol, int32_t *out_iters, void *out_U, void *out_X,
+                                           void *stream)
+{
+    if (!h) return KMPC_ERR_ARG;
+    if (B < 0) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_frenet: B=%d", B);
+    if (B == 0) return KMPC_OK;
+    if (!z0 || !k_poly || !v_target || !u_prev || !out_u0 || !out_status)
+        return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_frenet: null required buffer");
+    if (h->cfg.model != 1) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_frenet: handle was created with cfg.model = 0");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->cfg.dtype == KMPC_F64)
+        return solve_dev<double>(h, B, z0, k_poly, v_target, u_prev, warm_U, warm, out_u0, out_status, out_cost, out_viol,
+                                 out_iters, out_U, out_X, st);
+    return solve_dev<float>(h, B, z0, k_poly, v_target, u_prev, warm_U, warm, out_u0, out_status, out_cost, out_viol,
                             out_iters, out_U, out_X, st);
 }
 
@@ -242,6 +270,7 @@ extern "C" int32_t kmpc_solve_batch_host(kmpc_handle *h, int32_t B, const void *
     if (B == 0) return KMPC_OK;
     if (!z0 || !ref || !v_target || !u_prev || !out_u0 || !out_status)
         return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_host: null required buffer");
+    if (h->cfg.model != 0) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_host: Cartesian model only (use kmpc_solve_batch_frenet with device buffers)");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t es = h->cfg.dtype == KMPC_F64 ? 8 : 4;
     const size_t N = h->cfg.N, b = (size_t)B;

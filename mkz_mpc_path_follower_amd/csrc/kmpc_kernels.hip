@@ -27,9 +27,12 @@
 // per-lane stage record: lane k holds state k (k = 0..N) and input k (k < N)
 template <typename T> struct Stage {
     T a, d, v, x, y, psi, c, s, sinb, cosb, b1, b2, ex, ey, ep, ev;
+    T K, Kp, iden, dsdt;  // Frenet functor only: curvature, dK/ds, 1/(1 - e_y K), ds/dt at the stage
 };
 
-template <typename T, int NT> struct Solver {
+// MODEL 0: Cartesian kinematic bicycle (MKZMPCPathFollower.jl); MODEL 1: Frenet-frame variant (MKZMPCPathFollowerFrenet.jl:112-123),
+// states (s, e_y, e_psi, v) in the (x, y, psi, v) slots, zero cost references, Gauss-Newton Hessian only.
+template <typename T, int NT, int MODEL = 0> struct Solver {
     static constexpr int NV = (16 * NT + 63) / 64;       // n-vector slots per lane
     static constexpr int NF = (40 * NT - 2 + 63) / 64;   // form-vector slots per lane
     static constexpr int NTT = NT * (NT + 1) / 2;        // lower-triangular tiles
@@ -42,6 +45,7 @@ template <typename T, int NT> struct Solver {
     // problem data
     T x0, y0, psi0, v0, vt, up0, up1, xoff, yoff;
     T rx, ry, rp;  // reference at stage `lane`
+    T kp0, kp1, kp2, kp3;  // Frenet: K(s) = kp0 s^3 + kp1 s^2 + kp2 s + kp3
     T dt, dtc, Lb, rr_;
     T Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
 
@@ -61,14 +65,21 @@ template <typename T, int NT> struct Solver {
 
     DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)
     {
+        vt = vtp[b];
+        up0 = upp ? upp[2 * (size_t)b] : (T)0; up1 = upp ? upp[2 * (size_t)b + 1] : (T)0;
+        rx = ry = rp = (T)0;
+        kp0 = kp1 = kp2 = kp3 = (T)0;
+        psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
+        if (MODEL == 1) {  // `ref` carries k_poly [B,4]; (s, e_y) are not translation-invariant (K depends on s)
+            xoff = yoff = (T)0; x0 = z0[4 * (size_t)b]; y0 = z0[4 * (size_t)b + 1];
+            const T *kp = ref + 4 * (size_t)b;
+            kp0 = kp[0]; kp1 = kp[1]; kp2 = kp[2]; kp3 = kp[3];
+            return;
+        }
         // the NLP is invariant under a translation of (x, y): solve it in vehicle-centred coordinates (recorded paths live hundreds
         // of metres from their origin; positions would carry ~1e-13 m of rounding = ~1e-12 in the cost, above the Armijo
         // decrease of the last iterations); predictions are shifted back on output
         xoff = z0[4 * (size_t)b]; yoff = z0[4 * (size_t)b + 1]; x0 = (T)0; y0 = (T)0;
-        psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
-        vt = vtp[b];
-        up0 = upp ? upp[2 * (size_t)b] : (T)0; up1 = upp ? upp[2 * (size_t)b + 1] : (T)0;
-        rx = ry = rp = (T)0;
         if (lane <= N) {
             const T *r = ref + ((size_t)b * (N + 1) + lane) * 3;
             rx = r[0] - xoff; ry = r[1] - yoff; rp = r[2];
@@ -175,6 +186,7 @@ template <typename T, int NT> struct Solver {
     // ---- (a) roll-out + objective at U ----------------------------------------------------------
     DEV T eval(const T (&U)[NV], Stage<T> &S)
     {
+        if (MODEL == 1) return eval_frenet(U, S);
 #pragma unroll
         for (int i = 0; i < NV; ++i) { const int j = lane + 64 * i; if (j < n) xb[j] = U[i]; }
         WSYNC();
@@ -220,6 +232,7 @@ template <typename T, int NT> struct Solver {
     // ---- (b) costates, gradient (n-vector g) and per-stage scalars for the condensing loop -------
     DEV void linearize(const Stage<T> &S, bool exact, T (&g)[NV])
     {
+        if (MODEL == 1) { linearize_frenet(S, g); return; }
         const int k = lane;
         const bool st = k < N;
         const T lx = (T)2 * Cx * S.ex, ly = (T)2 * Cy * S.ey, lp = (T)2 * Cp * S.ep, lv = (T)2 * Cv * S.ev;
@@ -267,6 +280,7 @@ template <typename T, int NT> struct Solver {
     // acc[tile(ti,tj)] accumulates  sum_s G_s^T (2 Q_s + M_s) G_s  + delta-row terms  (unscaled)
     DEV void condense(bool exact, acc_t (&acc)[NTT])
     {
+        if (MODEL == 1) { condense_dense(acc); return; }
         const int kk = lane >> 4, c = lane & 15;
 #pragma unroll
         for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
@@ -327,6 +341,146 @@ template <typename T, int NT> struct Solver {
                         }
                     }
             }
+        }
+    }
+
+    // ================= Frenet functor (MODEL 1), MKZMPCPathFollowerFrenet.jl:112-123 =================================
+    // The dynamics couple s, e_y, e_psi through K(s) and 1/(1 - e_y K): no triangular cascade, so roll-out and costates are
+    // serial recursions over the stages on wave-uniform values (every lane runs them; lane k keeps stage k).
+    DEV T eval_frenet(const T (&U)[NV], Stage<T> &S)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int j = lane + 64 * i; if (j < n) xb[j] = U[i]; }
+        WSYNC();
+        const int k = lane;
+        const bool st = k < N;
+        T a = st ? xb[2 * k] : (T)0, d = st ? xb[2 * k + 1] : (T)0;
+        T an = (k + 1 < N) ? xb[2 * k + 2] : a, dn = (k + 1 < N) ? xb[2 * k + 3] : d;
+        S.a = a; S.d = d;
+        T sd, cd;
+        Real<T>::sincos_(d, &sd, &cd);
+        const T Dn = cd * cd + rr_ * rr_ * sd * sd;
+        const T rs = (T)1 / sqrt(Dn);
+        S.sinb = rr_ * sd * rs;  // sin(atan(r tan d))   (:113)
+        S.cosb = cd * rs;
+        S.b1 = rr_ / Dn;         // d beta / d d_f
+        S.b2 = (T)0;
+        if (st) { T *q = stg + KMPC_STG * k; q[13] = a; q[14] = S.sinb; q[15] = S.cosb; }  // slots 0..12 hold the stage Jacobians
+        WSYNC();
+        T s_ = x0, ey_ = y0, ep_ = psi0, v_ = v0;
+        S.x = S.y = S.psi = S.v = S.c = S.s = S.K = S.Kp = S.iden = S.dsdt = (T)0;
+        for (int kk = 0; kk <= N; ++kk) {
+            const T K = ((kp0 * s_ + kp1) * s_ + kp2) * s_ + kp3;               // :112
+            const T Kp = ((T)3 * kp0 * s_ + (T)2 * kp1) * s_ + kp2;
+            if (lane == kk) { S.x = s_; S.y = ey_; S.psi = ep_; S.v = v_; S.K = K; S.Kp = Kp; }
+            if (kk == N) break;
+            const T *q = stg + KMPC_STG * kk;
+            const T ak = q[13], sb = q[14], cbt = q[15];
+            T sp, cp;
+            Real<T>::sincos_(ep_, &sp, &cp);
+            const T c = cp * cbt - sp * sb, sn = sp * cbt + cp * sb;            // cos / sin(e_psi + beta)
+            const T iden = (T)1 / ((T)1 - ey_ * K), dsdt = v_ * c * iden;        // :114
+            if (lane == kk) { S.c = c; S.s = sn; S.iden = iden; S.dsdt = dsdt; }
+            s_ += dt * dsdt;                                                     // :118
+            ey_ += dt * (v_ * sn);                                               // :119
+            ep_ += dt * (v_ / Lb * sb - dsdt * K);                               // :120
+            v_ += dt * ak;                                                       // :121
+        }
+        WSYNC();
+        const bool cs = (k >= 1 && k <= N);
+        S.ex = cs ? S.x - rx : (T)0;
+        S.ey = cs ? S.y - ry : (T)0;
+        S.ep = cs ? S.psi - rp : (T)0;
+        S.ev = (k >= 1 && k <= N - 1) ? S.v - vt : (T)0;
+        T Jl = Cx * S.ex * S.ex + Cy * S.ey * S.ey + Cp * S.ep * S.ep + Cv * S.ev * S.ev;  // Frenet.jl:97-98 (C_x = 0)
+        if (st) Jl += Ca * a * a + Cd * d * d;
+        if (k < N - 1) Jl += Cda * (an - a) * (an - a) + Cdd * (dn - d) * (dn - d);
+        return wave_sum(Jl);
+    }
+
+    // stage record of the Frenet functor: A00 A01 A02 A03 A12 A13 A20 A21 A22 A23 Bs Bey Bep  (A11 = A33 = 1, B_v,acc = dt)
+    DEV void linearize_frenet(const Stage<T> &S, T (&g)[NV])
+    {
+        const int k = lane;
+        const bool st = k < N;
+        if (k <= N) {
+            T *q = stg + KMPC_STG * k;
+            const T v = S.v, c = S.c, sn = S.s, K = S.K, Kp = S.Kp, iden = S.iden, dsdt = S.dsdt, ey = S.y, b1 = S.b1;
+            const T ds_s = v * c * ey * Kp * iden * iden, ds_ey = v * c * K * iden * iden, ds_ep = -v * sn * iden, ds_v = c * iden,
+                    ds_d = -v * sn * iden * b1;
+            q[0] = st ? (T)1 + dt * ds_s : (T)0; q[1] = st ? dt * ds_ey : (T)0; q[2] = st ? dt * ds_ep : (T)0; q[3] = st ? dt * ds_v : (T)0;
+            q[4] = st ? dt * v * c : (T)0; q[5] = st ? dt * sn : (T)0;
+            q[6] = st ? dt * (-ds_s * K - dsdt * Kp) : (T)0; q[7] = st ? -dt * ds_ey * K : (T)0;
+            q[8] = st ? (T)1 - dt * ds_ep * K : (T)0; q[9] = st ? dt * (S.sinb / Lb - ds_v * K) : (T)0;
+            q[10] = st ? dt * ds_d : (T)0; q[11] = st ? dt * v * c * b1 : (T)0; q[12] = st ? dt * (v / Lb * S.cosb * b1 - ds_d * K) : (T)0;
+            T *l = wb + 4 * k;  // stage cost gradient (wb is scratch here; stage_form_weights rewrites it later)
+            l[0] = (T)2 * Cx * S.ex; l[1] = (T)2 * Cy * S.ey; l[2] = (T)2 * Cp * S.ep; l[3] = (T)2 * Cv * S.ev;
+        }
+        WSYNC();
+        T l0 = wb[4 * N], l1 = wb[4 * N + 1], l2 = wb[4 * N + 2], l3 = wb[4 * N + 3];  // costate of state N
+        for (int kk = N - 1; kk >= 0; --kk) {
+            const T *q = stg + KMPC_STG * kk;
+            if (lane == 0) { xb[2 * kk] = dt * l3; xb[2 * kk + 1] = q[10] * l0 + q[11] * l1 + q[12] * l2; }  // B_k^T lambda_{k+1}
+            const T t0 = q[0] * l0 + q[6] * l2;
+            const T t1 = q[1] * l0 + l1 + q[7] * l2;
+            const T t2 = q[2] * l0 + q[4] * l1 + q[8] * l2;
+            const T t3 = q[3] * l0 + q[5] * l1 + q[9] * l2 + l3;
+            const T *l = wb + 4 * kk;
+            l0 = t0 + l[0]; l1 = t1 + l[1]; l2 = t2 + l[2]; l3 = t3 + l[3];  // (unused after kk = 0)
+        }
+        WSYNC();
+        // input-cost terms, Frenet.jl:99-102 (same as the Cartesian model)
+        const T aprev = __shfl_up(S.a, 1), dprev = __shfl_up(S.d, 1);
+        const T anext = __shfl_down(S.a, 1), dnext = __shfl_down(S.d, 1);
+        if (st) {
+            T ga = xb[2 * k] + (T)2 * Ca * S.a, gd = xb[2 * k + 1] + (T)2 * Cd * S.d;
+            if (k >= 1) { ga += (T)2 * Cda * (S.a - aprev); gd += (T)2 * Cdd * (S.d - dprev); }
+            if (k < N - 1) { ga -= (T)2 * Cda * (anext - S.a); gd -= (T)2 * Cdd * (dnext - S.d); }
+            xb[2 * k] = ga; xb[2 * k + 1] = gd;
+        }
+        WSYNC();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int j = lane + 64 * i; g[i] = j < n ? xb[j] : (T)0; }
+        WSYNC();
+    }
+
+    // Gauss-Newton condensing with dense stage Jacobians: every lane keeps all four components of G for its column of each tile
+    // (replicated over the four kk groups); the MFMA fragment is component kk.
+    DEV void condense_dense(acc_t (&acc)[NTT])
+    {
+        const int kk = lane >> 4, c = lane & 15;
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        T g0[NT], g1[NT], g2[NT], g3[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) g0[t] = g1[t] = g2[t] = g3[t] = (T)0;
+        for (int s = 1; s <= N; ++s) {  // G_s = [A_{s-1} G_{s-1} | B_{s-1}]
+            const T *q = stg + KMPC_STG * (s - 1);
+            const T A00 = q[0], A01 = q[1], A02 = q[2], A03 = q[3], A12 = q[4], A13 = q[5], A20 = q[6], A21 = q[7], A22 = q[8], A23 = q[9];
+            const T Bs = q[10], Bey = q[11], Bep = q[12];
+            const int col0 = 2 * (s - 1);
+            const T Cvs = s <= N - 1 ? Cv : (T)0;
+            const T dco = kk == 0 ? (T)2 * Cx : (kk == 1 ? (T)2 * Cy : (kk == 2 ? (T)2 * Cp : (T)2 * Cvs));
+            T own[NT], bop[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const T n0 = A00 * g0[t] + A01 * g1[t] + A02 * g2[t] + A03 * g3[t];
+                const T n1 = g1[t] + A12 * g2[t] + A13 * g3[t];
+                const T n2 = A20 * g0[t] + A21 * g1[t] + A22 * g2[t] + A23 * g3[t];
+                g0[t] = n0; g1[t] = n1; g2[t] = n2;
+                const int col = 16 * t + c;
+                if (col == col0) { g0[t] = (T)0; g1[t] = (T)0; g2[t] = (T)0; g3[t] = dt; }
+                if (col == col0 + 1) { g0[t] = Bs; g1[t] = Bey; g2[t] = Bep; g3[t] = (T)0; }
+                own[t] = kk == 0 ? g0[t] : (kk == 1 ? g1[t] : (kk == 2 ? g2[t] : g3[t]));
+                bop[t] = dco * own[t];
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+                if (16 * ti < 2 * s) {
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj)
+                        acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[ti * (ti + 1) / 2 + tj]);
+                }
         }
     }
 
@@ -425,7 +579,8 @@ template <typename T, int NT> struct Solver {
             len = wave_sum(seg);
             kap = (readlane_(rp, N) - readlane_(rp, 1)) / fmax(len, (T)1e-6);
         }
-        const T vref = len / ((T)(N - 1) * dt);
+        if (MODEL == 1) kap = ((kp0 * x0 + kp1) * x0 + kp2) * x0 + kp3;  // Frenet: curvature of the polynomial at s0
+        const T vref = MODEL == 1 ? vt : len / ((T)(N - 1) * dt);
         const T sb = fmin(fmax((T)P.L_b * kap, (T)-0.9), (T)0.9);
         const T dff = fmin(fmax(atan(tan(asin(sb)) / rr), -frac * (T)P.steer_max), frac * (T)P.steer_max);
         const T aff = fmin(fmax(vref - v0, -frac * (T)P.a_max), frac * (T)P.a_max);
@@ -473,7 +628,7 @@ template <typename T, int NT> struct Solver {
         const T kappa_eps = 10, kappa_mu = (T)0.2, theta_mu = (T)1.5, tau_min = (T)0.99, kappa_sigma = (T)1e10,
                 eta_phi = (T)1e-8, s_max = 100;
         const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
-        const bool exact = P.hessian == 1;
+        const bool exact = P.hessian == 1 && MODEL == 0;  // the Frenet functor is Gauss-Newton only
         T U[NV], Uf[NV], g[NV], du[NV], rhs[NV], Ut[NV];
         T bu[NF], bl[NF], rlx[NF], su[NF], sl[NF], lu[NF], ll[NF], au[NF], aut[NF], dlu[NF], dll[NF], w[NF];
         bool fv[NF];
@@ -806,6 +961,17 @@ __global__ __launch_bounds__(64) void kmpc_solve_kernel(KP P, KIO<T> io)
     sv.solve(io, b);
 }
 
+template <typename T, int NT>
+__global__ __launch_bounds__(64) void kmpc_solve_frenet_kernel(KP P, KIO<T> io)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x >= P.B) return;
+    const int b = (int)blockIdx.x;
+    Solver<T, NT, 1> sv(P, smem);
+    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);  // io.ref = k_poly [B,4]
+    sv.solve(io, b);
+}
+
 // diagnostics: condensed Hessian / gradient / cost at a given U (used by the parity tests)
 template <typename T, int NT>
 __global__ __launch_bounds__(64) void kmpc_condense_kernel(KP P, KDbg<T> io)
@@ -866,6 +1032,16 @@ static hipError_t launch_solve_nt(const KP &P, const KIO<T> &io, hipStream_t st)
     return hipGetLastError();
 }
 template <typename T, int NT>
+static hipError_t launch_solve_frenet_nt(const KP &P, const KIO<T> &io, hipStream_t st)
+{
+    const size_t lds = kmpc_lds_bytes<T>(P.N, NT);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kmpc_solve_frenet_kernel<T, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((kmpc_solve_frenet_kernel<T, NT>), dim3(P.B), dim3(64), lds, st, P, io);
+    return hipGetLastError();
+}
+template <typename T, int NT>
 static hipError_t launch_condense_nt(const KP &P, const KDbg<T> &io, hipStream_t st)
 {
     const size_t lds = kmpc_lds_bytes<T>(P.N, NT);
@@ -893,6 +1069,16 @@ template <typename T> hipError_t kmpc_launch_solve(const KP &P, const KIO<T> &io
     const int NT = (2 * P.N + 15) / 16;
     KMPC_DISPATCH_NT(launch_solve_nt, P, io, st)
 }
+// Frenet functor: built for horizons up to N = 24 (the reference's is N = 8)
+template <typename T> hipError_t kmpc_launch_solve_frenet(const KP &P, const KIO<T> &io, hipStream_t st)
+{
+    switch ((2 * P.N + 15) / 16) {
+        case 1: return launch_solve_frenet_nt<T, 1>(P, io, st);
+        case 2: return launch_solve_frenet_nt<T, 2>(P, io, st);
+        case 3: return launch_solve_frenet_nt<T, 3>(P, io, st);
+        default: return hipErrorInvalidValue;
+    }
+}
 template <typename T> hipError_t kmpc_launch_condense(const KP &P, const KDbg<T> &io, hipStream_t st)
 {
     const int NT = (2 * P.N + 15) / 16;
@@ -906,6 +1092,8 @@ template <typename T> hipError_t kmpc_launch_probe(const T *a, const T *b, T *d,
 
 template hipError_t kmpc_launch_solve<double>(const KP &, const KIO<double> &, hipStream_t);
 template hipError_t kmpc_launch_solve<float>(const KP &, const KIO<float> &, hipStream_t);
+template hipError_t kmpc_launch_solve_frenet<double>(const KP &, const KIO<double> &, hipStream_t);
+template hipError_t kmpc_launch_solve_frenet<float>(const KP &, const KIO<float> &, hipStream_t);
 template hipError_t kmpc_launch_condense<double>(const KP &, const KDbg<double> &, hipStream_t);
 template hipError_t kmpc_launch_condense<float>(const KP &, const KDbg<float> &, hipStream_t);
 template hipError_t kmpc_launch_probe<double>(const double *, const double *, double *, hipStream_t);

@@ -98,6 +98,40 @@ class BatchMPC:
             o["warm_U"] = warm_U
         return o
 
+    def solve_frenet(self, z0, k_poly, v_target, u_prev, warm_U=None, warm=False, want_U=False, want_X=False, out=None):
+        """Frenet-frame variant (handle created with model=1): z0[B,4] = (s, e_y, e_psi, v), k_poly[B,4] curvature polynomial,
+        highest degree first; X[B,N+1,4] = (s, e_y, e_psi, v).  Otherwise as solve()."""
+        N = self.N
+        z0 = self._dev(z0, (len(z0), 4))
+        B = z0.shape[0]
+        k_poly = self._dev(k_poly, (B, 4))
+        v_target = self._dev(v_target, (B,))
+        u_prev = self._dev(u_prev, (B, 2))
+        if warm_U is not None:
+            warm_U = self._dev(warm_U, (B, N, 2))
+        o = out if out is not None else {}
+        kw = dict(dtype=self.dtype, device=self.device)
+        if "u0" not in o:
+            o["u0"] = torch.empty((B, 2), **kw)
+            o["status"] = torch.empty((B,), dtype=torch.int32, device=self.device)
+            o["cost"] = torch.empty((B,), **kw)
+            o["viol"] = torch.empty((B,), **kw)
+            o["iters"] = torch.empty((B,), dtype=torch.int32, device=self.device)
+        if want_U and "U" not in o:
+            o["U"] = torch.empty((B, N, 2), **kw)
+        if want_X and "X" not in o:
+            o["X"] = torch.empty((B, N + 1, 4), **kw)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self.lib.kmpc_solve_batch_frenet(self.h, B, _ptr(z0), _ptr(k_poly), _ptr(v_target), _ptr(u_prev),
+                                              _ptr(warm_U), 1 if (warm and warm_U is not None) else 0,
+                                              _ptr(o["u0"]), _ptr(o["status"]), _ptr(o["cost"]), _ptr(o["viol"]),
+                                              _ptr(o["iters"]), _ptr(o.get("U") if want_U else None),
+                                              _ptr(o.get("X") if want_X else None), stream)
+        _lib.check(rc, self.h)
+        if warm_U is not None:
+            o["warm_U"] = warm_U
+        return o
+
     # ---- diagnostics for tests ------------------------------------------------------------------
     def debug_condense(self, z0, ref, v_target, U, hessian=1):
         N = self.N

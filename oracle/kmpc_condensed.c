@@ -159,7 +159,7 @@ static void condense_parts(const kmpc_params *p, const kmpc_problem *q, const do
     double *G = (double *)calloc((size_t)4 * n, sizeof(double));
     double *P = (double *)calloc((size_t)(N + 2) * 4, sizeof(double));
     double A[16], B[8];
-    kmpc_rollout(p, q->z0, U, X);
+    kmpc_rollout_m(p, q->k_poly, q->z0, U, X);
     if (J) *J = kmpc_cost(p, q, U, X);
     memset(H, 0, (size_t)n * n * sizeof(double));
     if (S) memset(S, 0, (size_t)n * n * sizeof(double));
@@ -172,14 +172,14 @@ static void condense_parts(const kmpc_params *p, const kmpc_problem *q, const do
             pk[2] = 2.0 * p->C[2] * (X[4 * k + 2] - q->ref[3 * k + 2]);
             pk[3] = (k <= N - 1) ? 2.0 * p->C[3] * (X[4 * k + 3] - q->v_target) : 0.0;
             if (k < N) {
-                kmpc_stage_jac(p, X + 4 * k, U + 2 * k, A, B);
+                kmpc_stage_jac_m(p, q->k_poly, X + 4 * k, U + 2 * k, A, B);
                 for (int j = 0; j < 4; ++j)
                     for (int i = 0; i < 4; ++i) pk[j] += A[4 * i + j] * P[4 * (k + 1) + i];
             }
         }
     }
     for (int k = 0; k < N; ++k) {
-        kmpc_stage_jac(p, X + 4 * k, U + 2 * k, A, B);
+        kmpc_stage_jac_m(p, q->k_poly, X + 4 * k, U + 2 * k, A, B);
         if (hessian == 1) {
             double M[9];
             stage_hess(p, X + 4 * k, U + 2 * k, P + 4 * (k + 1), M);
@@ -312,9 +312,13 @@ static int interior_point(const kmpc_params *p, const kmpc_problem *q, double re
     memset(Uf, 0, (size_t)2 * N * sizeof(double));
     double len = 0.0;
     /* reference points 1..N only: point 0 is a dead input of the reference NLP (Q3) and must stay one here */
-    for (int k = 1; k < N; ++k) len += hypot(q->ref[3 * (k + 1)] - q->ref[3 * k], q->ref[3 * (k + 1) + 1] - q->ref[3 * k + 1]);
-    const double vref = len / ((N - 1) * p->dt);
-    const double kap = (q->ref[3 * N + 2] - q->ref[3 + 2]) / fmax(len, 1e-6);
+    if (p->model == 0)
+        for (int k = 1; k < N; ++k) len += hypot(q->ref[3 * (k + 1)] - q->ref[3 * k], q->ref[3 * (k + 1) + 1] - q->ref[3 * k + 1]);
+    const double s0 = q->z0[0];
+    /* Frenet model: the reference speed is v_target itself, the curvature K(s0) of the polynomial */
+    const double vref = p->model == 0 ? len / ((N - 1) * p->dt) : q->v_target;
+    const double kap = p->model == 0 ? (q->ref[3 * N + 2] - q->ref[3 + 2]) / fmax(len, 1e-6)
+                                     : ((q->k_poly[0] * s0 + q->k_poly[1]) * s0 + q->k_poly[2]) * s0 + q->k_poly[3];
     const double sb = fmin(fmax(p->L_b * kap, -0.9), 0.9);
     const double dff = fmin(fmax(atan(tan(asin(sb)) / r), -frac * p->steer_max), frac * p->steer_max);
     const double aff = fmin(fmax((vref - q->z0[3]) / T, -frac * p->a_max), frac * p->a_max);
@@ -355,13 +359,14 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
        than the Armijo decrease of the last iterations, which then stall at an error of ~1e-6 (closed-loop test). */
     kmpc_problem q_local = *q_in;
     double *ref_local = (double *)malloc((size_t)(N + 1) * 3 * sizeof(double));
-    const double x_off = q_in->z0[0], y_off = q_in->z0[1];
+    /* (the Frenet model is not translation-invariant in (s, e_y) -- K depends on s -- and its states are small anyway) */
+    const double x_off = p->model == 0 ? q_in->z0[0] : 0.0, y_off = p->model == 0 ? q_in->z0[1] : 0.0;
     for (int k = 0; k <= N; ++k) {
         ref_local[3 * k] = q_in->ref[3 * k] - x_off;
         ref_local[3 * k + 1] = q_in->ref[3 * k + 1] - y_off;
         ref_local[3 * k + 2] = q_in->ref[3 * k + 2];
     }
-    q_local.z0[0] = 0.0; q_local.z0[1] = 0.0;
+    q_local.z0[0] = q_in->z0[0] - x_off; q_local.z0[1] = q_in->z0[1] - y_off;
     q_local.ref = ref_local;
     const kmpc_problem *q = &q_local;
     forms_t F = {N, n, 2 * (N - 1), 5 * N - 2, p->dt};
@@ -429,8 +434,10 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
 
     for (int it = 0; it < o->max_iter; ++it) {
         /* linearise */
-        condense_parts(p, q, U, Hgn, o->hessian == 1 ? H : NULL, g, &J);
-        if (o->hessian == 1) for (int i = 0; i < n * n; ++i) H[i] += Hgn[i]; /* H = GN + second-order */
+        /* the Frenet functor is Gauss-Newton only (zero-residual tracking cost; no second-order terms restated) */
+        const int exact_h = o->hessian == 1 && p->model == 0;
+        condense_parts(p, q, U, Hgn, exact_h ? H : NULL, g, &J);
+        if (exact_h) for (int i = 0; i < n * n; ++i) H[i] += Hgn[i]; /* H = GN + second-order */
         if (it == 0) {
             /* Ipopt gradient-based scaling: nlp_scaling_max_gradient = 100 */
             double gmax = 0.0;
@@ -490,7 +497,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
                              (Gauss-Newton ignores negative curvature and leaves a saddle only slowly: N = 20 worst case 63 -> 35).
            Short horizons do best with 2, long ones (N = 50: <= 28 iterations instead of 100-190) with 1. */
         const int gn_hold_k = 2;
-        int use_gn = (o->hessian != 1) || gn_hold > 0;
+        int use_gn = !exact_h || gn_hold > 0;
         if (gn_hold > 0) --gn_hold;
         double reg = 0.0, hmax = 0.0;
         for (int j = 0; j < n; ++j) hmax = fmax(hmax, fabs(sc * H[j * n + j]));
@@ -590,7 +597,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
             for (int l = 0; l < (pass == 0 && mu_strategy == 1 ? 1 : o->max_ls); ++l, alpha *= 0.5) {
                 ++n_ls;
                 for (int j = 0; j < n; ++j) Ut[j] = U[j] + alpha * du[j];
-                kmpc_rollout(p, q->z0, Ut, Xt);
+                kmpc_rollout_m(p, q->k_poly, q->z0, Ut, Xt);
                 double phi = sc * kmpc_cost(p, q, Ut, Xt);
                 int ok = 1;
                 for (int f = 0; f < nf; ++f) {
@@ -627,7 +634,7 @@ finish:
         status = KMPC_OPTIMAL;
     }
     free(Ubest);
-    kmpc_rollout(p, q->z0, U, Xl);
+    kmpc_rollout_m(p, q->k_poly, q->z0, U, Xl);
     if (X)
         for (int k = 0; k <= N; ++k) {
             X[4 * k] = Xl[4 * k] + x_off; X[4 * k + 1] = Xl[4 * k + 1] + y_off;
@@ -674,10 +681,15 @@ static void *worker(void *arg)
 {
     job_t *j = (job_t *)arg;
     const int N = j->p->N;
+    double *zeros = (double *)calloc((size_t)(N + 1) * 3, sizeof(double));
     for (int b = j->b0; b < j->b1; ++b) {
         kmpc_problem q;
+        memset(&q, 0, sizeof q);
         memcpy(q.z0, j->z0 + 4 * (size_t)b, sizeof q.z0);
-        q.ref = j->ref + (size_t)b * (N + 1) * 3;
+        if (j->p->model == 1) { /* Frenet: `ref` carries k_poly [B,4]; the cost references are zero */
+            memcpy(q.k_poly, j->ref + 4 * (size_t)b, sizeof q.k_poly);
+            q.ref = zeros;
+        } else q.ref = j->ref + (size_t)b * (N + 1) * 3;
         q.v_target = j->vt[b];
         q.u_prev[0] = j->up[2 * (size_t)b];
         q.u_prev[1] = j->up[2 * (size_t)b + 1];
@@ -689,6 +701,7 @@ static void *worker(void *arg)
         if (j->viol) j->viol[b] = r.viol;
         if (j->iters) j->iters[b] = r.iters;
     }
+    free(zeros);
     return NULL;
 }
 

@@ -29,6 +29,15 @@ void kmpc_params_default(kmpc_params *p, int N)
     p->C[5] = 1000.0; /* C_ddf  :57 */
     p->C[6] = 0.0;    /* C_acc  :58 */
     p->C[7] = 0.0;    /* C_df   :59 */
+    p->model = 0;
+}
+
+/* defaults of MKZMPCPathFollowerFrenet.jl:27-59: same constants, weights C_ey 9, C_epsi 10, C_ev 0.5, C_dacc 100, C_ddf 1000 */
+void kmpc_params_default_frenet(kmpc_params *p, int N)
+{
+    kmpc_params_default(p, N);
+    p->model = 1;
+    p->C[0] = 0.0; p->C[1] = 9.0; p->C[2] = 10.0; p->C[3] = 0.5;
 }
 
 int kmpc_n(const kmpc_params *p) { return 2 * p->N; }
@@ -71,6 +80,56 @@ void kmpc_rollout(const kmpc_params *p, const double z0[4], const double *U, dou
     for (int k = 0; k < p->N; ++k) kmpc_step(p, X + 4 * k, U + 2 * k, X + 4 * (k + 1));
 }
 
+/* ---- Frenet-frame model, MKZMPCPathFollowerFrenet.jl:112-123 (z = s, e_y, e_psi, v) ---------------------------- */
+static void frenet_step(const kmpc_params *p, const double *kp, const double z[4], const double u[2], double zn[4])
+{
+    const double r = p->L_b / (p->L_a + p->L_b);
+    const double s = z[0], ey = z[1], ep = z[2], v = z[3];
+    const double K = ((kp[0] * s + kp[1]) * s + kp[2]) * s + kp[3];          /* :112 */
+    const double beta = atan(r * tan(u[1]));                                  /* :113 */
+    const double dsdt = v * cos(ep + beta) / (1.0 - ey * K);                  /* :114 */
+    zn[0] = s + p->dt * dsdt;                                                 /* :118 */
+    zn[1] = ey + p->dt * (v * sin(ep + beta));                                /* :119 */
+    zn[2] = ep + p->dt * (v / p->L_b * sin(beta) - dsdt * K);                 /* :120 */
+    zn[3] = v + p->dt * u[0];                                                 /* :121 */
+}
+
+static void frenet_stage_jac(const kmpc_params *p, const double *kp, const double z[4], const double u[2], double A[16], double B[8])
+{
+    const double r = p->L_b / (p->L_a + p->L_b), dt = p->dt;
+    const double s = z[0], ey = z[1], ep = z[2], v = z[3];
+    const double K = ((kp[0] * s + kp[1]) * s + kp[2]) * s + kp[3], Kp = (3.0 * kp[0] * s + 2.0 * kp[1]) * s + kp[2];
+    const double td = tan(u[1]), beta = atan(r * td), db = r * (1.0 + td * td) / (1.0 + r * r * td * td);
+    const double c = cos(ep + beta), sn = sin(ep + beta), den = 1.0 - ey * K;
+    const double dsdt = v * c / den;
+    const double ds_s = v * c * ey * Kp / (den * den), ds_ey = v * c * K / (den * den), ds_ep = -v * sn / den, ds_v = c / den,
+                 ds_d = -v * sn / den * db;
+    memset(A, 0, 16 * sizeof(double));
+    memset(B, 0, 8 * sizeof(double));
+    A[0] = 1.0 + dt * ds_s; A[1] = dt * ds_ey; A[2] = dt * ds_ep; A[3] = dt * ds_v;
+    A[5] = 1.0; A[6] = dt * v * c; A[7] = dt * sn;
+    A[8] = dt * (-ds_s * K - dsdt * Kp); A[9] = -dt * ds_ey * K; A[10] = 1.0 - dt * ds_ep * K; A[11] = dt * (sin(beta) / p->L_b - ds_v * K);
+    A[15] = 1.0;
+    B[1] = dt * ds_d;
+    B[3] = dt * v * c * db;
+    B[5] = dt * (v / p->L_b * cos(beta) * db - ds_d * K);
+    B[6] = dt;
+}
+
+void kmpc_step_m(const kmpc_params *p, const double *kp, const double z[4], const double u[2], double zn[4])
+{
+    if (p->model == 1) frenet_step(p, kp, z, u, zn); else kmpc_step(p, z, u, zn);
+}
+void kmpc_stage_jac_m(const kmpc_params *p, const double *kp, const double z[4], const double u[2], double A[16], double B[8])
+{
+    if (p->model == 1) frenet_stage_jac(p, kp, z, u, A, B); else kmpc_stage_jac(p, z, u, A, B);
+}
+void kmpc_rollout_m(const kmpc_params *p, const double *kp, const double z0[4], const double *U, double *X)
+{
+    memcpy(X, z0, 4 * sizeof(double));
+    for (int k = 0; k < p->N; ++k) kmpc_step_m(p, kp, X + 4 * k, U + 2 * k, X + 4 * (k + 1));
+}
+
 /* :97-103.  Julia i=2..N+1 -> k=1..N (position, heading); i=2..N -> k=1..N-1 (speed, Q3) */
 double kmpc_cost(const kmpc_params *p, const kmpc_problem *q, const double *U, const double *X)
 {
@@ -103,7 +162,7 @@ void kmpc_grad(const kmpc_params *p, const kmpc_problem *q, const double *U, con
     lam[2] = 2.0 * p->C[2] * (X[4 * N + 2] - q->ref[3 * N + 2]);
     lam[3] = 0.0;
     for (int k = N - 1; k >= 0; --k) {
-        kmpc_stage_jac(p, X + 4 * k, U + 2 * k, A, B);
+        kmpc_stage_jac_m(p, q->k_poly, X + 4 * k, U + 2 * k, A, B);
         for (int j = 0; j < 2; ++j) {
             double s = 0.0;
             for (int i = 0; i < 4; ++i) s += B[2 * i + j] * lam[i];
@@ -208,7 +267,7 @@ void kmpc_certify(const kmpc_params *p, const kmpc_problem *q, const double *U, 
     double *X = (double *)malloc((size_t)(N + 1) * 4 * sizeof(double));
     double *g = (double *)malloc((size_t)n * sizeof(double));
     kmpc_ineq(p, q, 0.0, A, b);
-    kmpc_rollout(p, q->z0, U, X);
+    kmpc_rollout_m(p, q->k_poly, q->z0, U, X);
     kmpc_grad(p, q, U, X, g);
     double viol = -INFINITY, comp = 0.0, lmin = INFINITY;
     for (int i = 0; i < m; ++i) {

@@ -38,6 +38,10 @@ typedef struct kmpc_params {
     /* cost weights in update_cost() argument order (:158-169):
        C_x, C_y, C_psi, C_v, C_dacc, C_ddf, C_acc, C_df */
     double C[8];
+    /* 0 = Cartesian model of MKZMPCPathFollower.jl; 1 = Frenet-frame model of MKZMPCPathFollowerFrenet.jl: states (s, e_y, e_psi, v),
+       dynamics :114-123 with the curvature polynomial K(s) (:112), cost :97-103 = the same form with zero references and
+       C = (0, C_ey, C_epsi, C_ev, C_dacc, C_ddf, C_acc, C_df) */
+    int model;
 } kmpc_params;
 
 typedef struct kmpc_problem {
@@ -45,10 +49,12 @@ typedef struct kmpc_problem {
     const double *ref;   /* [(N+1)*3] x_r, y_r, psi_r per stage (stage 0 is a dead input, Q3) */
     double v_target;     /* update_reference 4th arg :146 */
     double u_prev[2];    /* acc_current, d_f_current (update_current_input takes them steer-first, :151) */
+    double k_poly[4];    /* Frenet model only: K(s) = k[0] s^3 + k[1] s^2 + k[2] s + k[3]  (highest degree first, Frenet.jl:38-39) */
 } kmpc_problem;
 
 /* defaults of MKZMPCPathFollower.jl:28-59 with the given horizon */
 void kmpc_params_default(kmpc_params *p, int N);
+void kmpc_params_default_frenet(kmpc_params *p, int N);
 
 /* number of decision inputs n = 2N and one-sided inequality rows m = 10N-4 */
 int kmpc_n(const kmpc_params *p);
@@ -56,6 +62,10 @@ int kmpc_m(const kmpc_params *p);
 
 /* one forward-Euler step of the CoG kinematic bicycle, :115-122 */
 void kmpc_step(const kmpc_params *p, const double z[4], const double u[2], double zn[4]);
+/* the same for the Frenet model (needs the curvature polynomial) */
+void kmpc_step_m(const kmpc_params *p, const double *k_poly, const double z[4], const double u[2], double zn[4]);
+void kmpc_stage_jac_m(const kmpc_params *p, const double *k_poly, const double z[4], const double u[2], double A[16], double B[8]);
+void kmpc_rollout_m(const kmpc_params *p, const double *k_poly, const double z0[4], const double *U, double *X);
 /* stage Jacobians A = df/dz (4x4 row-major), B = df/du (4x2 row-major, columns acc, d_f) */
 void kmpc_stage_jac(const kmpc_params *p, const double z[4], const double u[2], double A[16], double B[8]);
 /* X[0..3] = z0, X[4(k+1)..] = f(X[4k..], U[2k..]) */

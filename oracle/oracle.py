@@ -23,12 +23,12 @@ class Params(C.Structure):
                 ("L_a", C.c_double), ("L_b", C.c_double),
                 ("steer_max", C.c_double), ("steer_dmax", C.c_double),
                 ("a_max", C.c_double), ("a_dmax", C.c_double),
-                ("v_min", C.c_double), ("v_max", C.c_double), ("C", C.c_double * 8)]
+                ("v_min", C.c_double), ("v_max", C.c_double), ("C", C.c_double * 8), ("model", C.c_int)]
 
 
 class Problem(C.Structure):
     _fields_ = [("z0", C.c_double * 4), ("ref", c_double_p), ("v_target", C.c_double),
-                ("u_prev", C.c_double * 2)]
+                ("u_prev", C.c_double * 2), ("k_poly", C.c_double * 4)]
 
 
 class Opts(C.Structure):
@@ -56,7 +56,10 @@ def lib():
     if _LIB is None:
         L = C.CDLL(build())
         L.kmpc_params_default.argtypes = [C.POINTER(Params), C.c_int]
+        L.kmpc_params_default_frenet.argtypes = [C.POINTER(Params), C.c_int]
         L.kmpc_rollout.argtypes = [C.POINTER(Params), c_double_p, c_double_p, c_double_p]
+        L.kmpc_rollout_m.argtypes = [C.POINTER(Params), c_double_p, c_double_p, c_double_p, c_double_p]
+        L.kmpc_stage_jac_m.argtypes = [C.POINTER(Params), c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
         L.kmpc_cost.argtypes = [C.POINTER(Params), C.POINTER(Problem), c_double_p, c_double_p]
         L.kmpc_cost.restype = C.c_double
         L.kmpc_grad.argtypes = [C.POINTER(Params), C.POINTER(Problem), c_double_p, c_double_p, c_double_p]
@@ -81,9 +84,11 @@ def _p(a):
     return a.ctypes.data_as(c_double_p)
 
 
-def params(N=8, weights=None, **kw):
+def params(N=8, weights=None, model=0, **kw):
+    """model 0: MKZMPCPathFollower.jl (Cartesian), 1: MKZMPCPathFollowerFrenet.jl (weights then are the full 8-vector
+    (0, C_ey, C_epsi, C_ev, C_dacc, C_ddf, C_acc, C_df))"""
     p = Params()
-    lib().kmpc_params_default(C.byref(p), int(N))
+    (lib().kmpc_params_default_frenet if model == 1 else lib().kmpc_params_default)(C.byref(p), int(N))
     if weights is not None:
         for i, w in enumerate(weights):
             p.C[i] = float(w)
@@ -103,8 +108,10 @@ def opts(**kw):
 class _Prob:
     """keeps the numpy reference array alive next to the ctypes struct"""
 
-    def __init__(self, p, z0, ref, v_target, u_prev):
+    def __init__(self, p, z0, ref, v_target, u_prev, k_poly=None):
         N = p.N
+        if ref is None:  # Frenet model: the cost has zero references
+            ref = np.zeros((N + 1, 3))
         self.ref = np.ascontiguousarray(ref, dtype=np.float64).reshape(N + 1, 3)
         self.c = Problem()
         for i in range(4):
@@ -113,30 +120,38 @@ class _Prob:
         self.c.v_target = float(v_target)
         self.c.u_prev[0] = float(u_prev[0])
         self.c.u_prev[1] = float(u_prev[1])
+        for i in range(4):
+            self.c.k_poly[i] = 0.0 if k_poly is None else float(k_poly[i])
 
 
-def problem(p, z0, ref, v_target, u_prev=(0.0, 0.0)):
-    return _Prob(p, z0, ref, v_target, u_prev)
+def problem(p, z0, ref, v_target, u_prev=(0.0, 0.0), k_poly=None):
+    return _Prob(p, z0, ref, v_target, u_prev, k_poly)
 
 
-def rollout(p, z0, U):
+def problem_frenet(p, z0, k_poly, v_target, u_prev=(0.0, 0.0)):
+    """z0 = (s, e_y, e_psi, v); k_poly highest degree first (MKZMPCPathFollowerFrenet.jl:132-147)"""
+    return _Prob(p, z0, None, v_target, u_prev, k_poly)
+
+
+def rollout(p, z0, U, k_poly=None):
     N = p.N
     U = np.ascontiguousarray(U, dtype=np.float64).reshape(2 * N)
     z0 = np.ascontiguousarray(z0, dtype=np.float64)
     X = np.empty((N + 1, 4))
-    lib().kmpc_rollout(C.byref(p), _p(z0), _p(U), _p(X))
+    kp = np.zeros(4) if k_poly is None else np.ascontiguousarray(k_poly, dtype=np.float64)
+    lib().kmpc_rollout_m(C.byref(p), _p(kp), _p(z0), _p(U), _p(X))
     return X
 
 
 def cost(p, q, U):
     U = np.ascontiguousarray(U, dtype=np.float64).reshape(2 * p.N)
-    X = rollout(p, np.array(q.c.z0[:]), U)
+    X = rollout(p, np.array(q.c.z0[:]), U, np.array(q.c.k_poly[:]))
     return lib().kmpc_cost(C.byref(p), C.byref(q.c), _p(U), _p(X))
 
 
 def grad(p, q, U):
     U = np.ascontiguousarray(U, dtype=np.float64).reshape(2 * p.N)
-    X = rollout(p, np.array(q.c.z0[:]), U)
+    X = rollout(p, np.array(q.c.z0[:]), U, np.array(q.c.k_poly[:]))
     g = np.empty(2 * p.N)
     lib().kmpc_grad(C.byref(p), C.byref(q.c), _p(U), _p(X), _p(g))
     return g
