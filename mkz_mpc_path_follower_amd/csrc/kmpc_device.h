@@ -40,7 +40,8 @@ inline size_t kmpc_lds_bytes(int N, int NT)
 {
     const int n = 2 * N;
     const int NF = (40 * NT - 2 + 63) / 64;
-    size_t elems = (size_t)n * (n + 1) + (size_t)KMPC_STG * (N + 1) + 16 * NT + 64 * NF + 64 + 16 * NT;
+    // K (n x (n+1)), stage records, xb, wb, cb, dinv, panel scratch of the blocked Cholesky (64 NT)
+    size_t elems = (size_t)n * (n + 1) + (size_t)KMPC_STG * (N + 1) + 16 * NT + 64 * NF + 64 + 16 * NT + 64 * NT;
     elems = (elems + 1) & ~(size_t)1;
     return elems * sizeof(T);
 }
