@@ -41,7 +41,9 @@ inline size_t kmpc_lds_bytes(int N, int NT)
     const int n = 2 * N;
     const int NF = (40 * NT - 2 + 63) / 64;
     // K (n x (n+1)), stage records, xb, wb, cb, dinv, panel scratch of the blocked Cholesky (64 NT)
-    size_t elems = (size_t)n * (n + 1) + (size_t)KMPC_STG * (N + 1) + 16 * NT + 64 * NF + 64 + 16 * NT + 64 * NT;
+    // from NT = 5 the matrix is padded to whole 16x16 tiles (the Hessian tiles are accumulated in it without bounds checks)
+    const size_t kelems = NT >= 5 ? (size_t)(16 * NT) * (16 * NT + 1) : (size_t)n * (n + 1);
+    size_t elems = kelems + (size_t)KMPC_STG * (N + 1) + 16 * NT + 64 * NF + 64 + 16 * NT + 64 * NT;
     elems = (elems + 1) & ~(size_t)1;
     return elems * sizeof(T);
 }

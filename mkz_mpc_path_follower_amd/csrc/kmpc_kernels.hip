@@ -36,6 +36,10 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
     static constexpr int NV = (16 * NT + 63) / 64;       // n-vector slots per lane
     static constexpr int NF = (40 * NT - 2 + 63) / 64;   // form-vector slots per lane
     static constexpr int NTT = NT * (NT + 1) / 2;        // lower-triangular tiles
+    // From NT = 5 on the condensed Hessian no longer fits in registers next to the solver state (28 tiles = 224 fp64 VGPRs at NT = 7:
+    // 1146 spilled registers, measured): its tiles are accumulated in LDS, in place in the K matrix, one tile row at a time.
+    static constexpr bool LDSACC = NT >= 5;
+    static constexpr int NACC = LDSACC ? 1 : NTT;
     typedef typename Real<T>::acc_t acc_t;
 
     STAMP_MEMBERS
@@ -50,10 +54,10 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
     T Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
 
     DEV Solver(const KP &p, unsigned char *smem)
-        : P(p), lane(threadIdx.x), N(p.N), n(2 * p.N), R(2 * (p.N - 1)), nf(5 * p.N - 2), ld(2 * p.N + 1)
+        : P(p), lane(threadIdx.x), N(p.N), n(2 * p.N), R(2 * (p.N - 1)), nf(5 * p.N - 2), ld(NT >= 5 ? 16 * NT + 1 : 2 * p.N + 1)
     {
         Km = reinterpret_cast<T *>(smem);
-        stg = Km + n * ld;
+        stg = Km + (NT >= 5 ? 16 * NT : n) * ld;
         xb = stg + KMPC_STG * (N + 1);
         wb = xb + 16 * NT;
         cb = wb + 64 * NF;
@@ -279,12 +283,32 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
 
     // ---- (c) condensing on the matrix cores ------------------------------------------------------
     // acc[tile(ti,tj)] accumulates  sum_s G_s^T (2 Q_s + M_s) G_s  + delta-row terms  (unscaled)
-    DEV void condense(bool exact, acc_t (&acc)[NTT])
+    // tile (ti, tj) of the tile-padded LDS matrix in MFMA C layout (LDSACC only: the matrix has 16 NT rows, so no bounds checks)
+    DEV acc_t tile_load(int ti, int tj) const
     {
-        if (MODEL == 1) { condense_dense(acc); return; }
-        const int kk = lane >> 4, c = lane & 15;
+        const T *base = Km + (16 * ti) * ld + 16 * tj + (lane & 15);
+        acc_t a;
 #pragma unroll
-        for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        for (int r = 0; r < 4; ++r) a[r] = base[Real<T>::row_of(lane, r) * ld];
+        return a;
+    }
+    DEV void tile_store(int ti, int tj, const acc_t &a)
+    {
+        T *base = Km + (16 * ti) * ld + 16 * tj + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) base[Real<T>::row_of(lane, r) * ld] = a[r];
+    }
+    DEV void condense(bool exact, acc_t (&acc)[NACC])
+    {
+        if constexpr (MODEL == 1) { condense_dense(acc); return; }
+        const int kk = lane >> 4, c = lane & 15;
+        if constexpr (LDSACC) {
+            for (int e = lane; e < 16 * NT * ld; e += 64) Km[e] = (T)0;
+            WSYNC();
+        } else {
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        }
         T own[NT], gps[NT], gv[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) own[t] = gps[t] = gv[t] = (T)0;
@@ -315,12 +339,36 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
                     if (16 * ti < 2 * s) {
+                        if constexpr (LDSACC) {  // one tile row at a time through registers
+                            acc_t row[NT];
 #pragma unroll
-                        for (int tj = 0; tj <= ti; ++tj)
-                            acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[ti * (ti + 1) / 2 + tj]);
+                            for (int tj = 0; tj <= ti; ++tj) row[tj] = tile_load(ti, tj);
+#pragma unroll
+                            for (int tj = 0; tj <= ti; ++tj) row[tj] = Real<T>::mfma(own[ti], bop[tj], row[tj]);
+#pragma unroll
+                            for (int tj = 0; tj <= ti; ++tj) tile_store(ti, tj, row[tj]);
+                        } else {
+#pragma unroll
+                            for (int tj = 0; tj <= ti; ++tj)
+                                acc[(LDSACC ? 0 : ti * (ti + 1) / 2 + tj)] = Real<T>::mfma(own[ti], bop[tj], acc[(LDSACC ? 0 : ti * (ti + 1) / 2 + tj)]);
+                        }
                     }
             }
-            if (exact && s < N) {  // row 2s+1 (d_f of stage s) of the second-order term
+            if (LDSACC && exact && s < N) {  // row 2s+1 of the second-order term, straight into the LDS matrix (lanes kk == 0: one per column)
+                const T *qs = stg + KMPC_STG * s;
+                const T mpd = qs[10], mvd = qs[11], mdd = qs[12];
+                const int rho = 2 * s + 1;
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+                    const int col = 16 * tj + c;
+                    if (kk == 0 && col <= rho) {
+                        T val = mpd * gps[tj] + mvd * gv[tj];
+                        if (col == rho) val += mdd;
+                        Km[rho * ld + col] += val;
+                    }
+                }
+            }
+            if (!LDSACC && exact && s < N) {  // row 2s+1 (d_f of stage s) of the second-order term
                 const T *qs = stg + KMPC_STG * s;
                 const T mpd = qs[10], mvd = qs[11], mdd = qs[12];
                 const int rho = 2 * s + 1, rt = rho >> 4, rr = rho & 15;
@@ -334,7 +382,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                             T val = mpd * gps[tj] + mvd * gv[tj];
                             if (tj == ti && c == rr) val += mdd;
                             if (!mine) val = (T)0;
-                            acc_t &A = acc[ti * (ti + 1) / 2 + tj];
+                            acc_t &A = acc[LDSACC ? 0 : ti * (ti + 1) / 2 + tj];
                             A[0] += reg == 0 ? val : (T)0;
                             A[1] += reg == 1 ? val : (T)0;
                             A[2] += reg == 2 ? val : (T)0;
@@ -447,11 +495,12 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
 
     // Gauss-Newton condensing with dense stage Jacobians: every lane keeps all four components of G for its column of each tile
     // (replicated over the four kk groups); the MFMA fragment is component kk.
-    DEV void condense_dense(acc_t (&acc)[NTT])
+    DEV void condense_dense(acc_t (&acc)[NACC])
     {
+        static_assert(!(MODEL == 1 && LDSACC), "the Frenet functor keeps its tiles in registers (NT <= 4)");
         const int kk = lane >> 4, c = lane & 15;
 #pragma unroll
-        for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        for (int t = 0; t < NACC; ++t) acc[t] = acc_t{0, 0, 0, 0};
         T g0[NT], g1[NT], g2[NT], g3[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) g0[t] = g1[t] = g2[t] = g3[t] = (T)0;
@@ -480,15 +529,16 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                 if (16 * ti < 2 * s) {
 #pragma unroll
                     for (int tj = 0; tj <= ti; ++tj)
-                        acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[ti * (ti + 1) / 2 + tj]);
+                        acc[LDSACC ? 0 : ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[LDSACC ? 0 : ti * (ti + 1) / 2 + tj]);
                 }
         }
     }
 
     // ---- (d) K (lower triangle, LDS) = sc*(H + input Hessian) + A^T W A + reg*I -----------------
-    DEV void build_K(const acc_t (&acc)[NTT], T sc, T reg)
+    DEV void build_K(const acc_t (&acc)[NACC], T sc, T reg)
     {
         const int c = lane & 15;
+        if constexpr (LDSACC) WSYNC();
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -497,7 +547,8 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + Real<T>::row_of(lane, r), col = 16 * tj + c;
                     if (row < n && col <= row) {
-                        T v = sc * (acc[ti * (ti + 1) / 2 + tj][r] + input_hess(row, col)) + gram_entry(row, col);
+                        const T h = LDSACC ? Km[row * ld + col] : acc[LDSACC ? 0 : ti * (ti + 1) / 2 + tj][r];  // in place when the tiles live in LDS
+                        T v = sc * (h + input_hess(row, col)) + gram_entry(row, col);
                         if (row == col) v += reg;
                         Km[row * ld + col] = v;
                     }
@@ -708,7 +759,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         for (int i = 0; i < NV; ++i) Ubest[i] = (T)0;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, err0 = 0;
         Stage<T> S, St;
-        acc_t acc[NTT];
+        acc_t acc[NACC];
         STAMP_DECL
 
         const bool feas = interior_point(Uf);
@@ -825,11 +876,16 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                         need_condense = false;
                         if (indef == 1 && use_exact) {  // max |sc * H_jj| over the diagonal of the tiles
                             T hm = 0;
+                            if constexpr (LDSACC) {
+                                WSYNC();
+                                for (int j = lane; j < n; j += 64) hm = fmax(hm, fabs(sc * Km[j * ld + j]));
+                            } else {
 #pragma unroll
-                            for (int ti = 0; ti < NT; ++ti)
+                                for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[ti * (ti + 1) / 2 + ti][r]));
+                                    for (int r = 0; r < 4; ++r)
+                                        if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[LDSACC ? 0 : ti * (ti + 1) / 2 + ti][r]));
+                            }
                             hmax = wave_max(hm);
                         }
                     }
@@ -840,6 +896,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                     const bool okc = cholesky();
                     STAMP(5);
                     if (okc) { factored = true; if (use_exact && reg > 0) dw_last = reg; if (use_exact) dw_spec = reg; break; }
+                    if (LDSACC) need_condense = true;  // the tiles lived in the matrix the factorisation just overwrote
                     if (use_exact && indef == 1) {
                         if (reg == 0) reg = dw_last > 0 ? fmax((T)1e-10 * hmax, dw_last / 3) : (T)1e-4 * hmax;
                         else reg *= dw_last > 0 ? (T)8 : (T)100;
@@ -1054,8 +1111,9 @@ __global__ __launch_bounds__(64) void kmpc_condense_kernel(KP P, KDbg<T> io)
     Stage<T> S;
     const T J = sv.eval(U, S);
     sv.linearize(S, P.hessian == 1, g);
-    typename SV::acc_t acc[SV::NTT];
+    typename SV::acc_t acc[SV::NACC];
     sv.condense(P.hessian == 1, acc);
+    if (SV::LDSACC) WSYNC();
     T *H = io.H + (size_t)b * n * n;
     const int c = lane & 15;
 #pragma unroll
@@ -1066,7 +1124,7 @@ __global__ __launch_bounds__(64) void kmpc_condense_kernel(KP P, KDbg<T> io)
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + Real<T>::row_of(lane, r), col = 16 * tj + c;
                 if (row < n && col <= row) {
-                    const T v = acc[ti * (ti + 1) / 2 + tj][r] + sv.input_hess(row, col);
+                    const T v = (SV::LDSACC ? sv.Km[row * sv.ld + col] : acc[SV::LDSACC ? 0 : ti * (ti + 1) / 2 + tj][r]) + sv.input_hess(row, col);
                     H[row * n + col] = v;
                     H[col * n + row] = v;
                 }
