@@ -758,7 +758,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
 #pragma unroll
         for (int i = 0; i < NV; ++i) Ubest[i] = (T)0;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, err0 = 0;
-        Stage<T> S, St;
+        Stage<T> S;  // one stage record: trial evaluations overwrite it, the returned point is re-evaluated at the end
         acc_t acc[NACC];
         STAMP_DECL
 
@@ -994,7 +994,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                     for (int l = 0; l < nls; ++l, alpha *= (T)0.5) {
 #pragma unroll
                         for (int i = 0; i < NV; ++i) Ut[i] = U[i] + alpha * du[i];
-                        Jt = eval(Ut, St);
+                        Jt = eval(Ut, S);
                         T lgt = 0;
                         bool ok = true;
 #pragma unroll
@@ -1013,7 +1013,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                 if (!accepted) { status = err0 <= (T)100 * tol ? 0 : 3; break; }  // acceptable level reached
 #pragma unroll
                 for (int i = 0; i < NV; ++i) U[i] = Ut[i];
-                S = St; J = Jt;
+                J = Jt;
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
@@ -1030,8 +1030,8 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
 #pragma unroll
             for (int i = 0; i < NV; ++i) U[i] = Ubest[i];
             status = 0;
-            J = eval(U, S);
         }
+        if (status != 2) J = eval(U, S);  // stage record of the returned point (the last trial may have been rejected)
         // ---- outputs ----------------------------------------------------------------------------
         forms_apply(U, au);
         T viol = -(T)1e30;
