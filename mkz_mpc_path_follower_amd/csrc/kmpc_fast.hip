@@ -662,7 +662,8 @@ template <typename T, int N> struct FastSolver {
         const T dff = fmin(fmax(atan(tan(asin(sb)) / rr), -frac * (T)P.steer_max), frac * (T)P.steer_max);
         const T aff = fmin(fmax(vref - v0, -frac * (T)P.a_max), frac * (T)P.a_max);
         T u0[2];
-        bool ok = true;
+        // Q5: v[1] = v0 is itself bounded in the reference model -> any v0 outside the (relaxed) speed bounds is infeasible
+        bool ok = v0 >= (T)P.v_min - relax * fmax((T)1, fabs((T)P.v_min)) && v0 <= (T)P.v_max + relax * fmax((T)1, fabs((T)P.v_max));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const T ub = j ? (T)P.steer_max : (T)P.a_max;

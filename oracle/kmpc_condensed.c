@@ -310,6 +310,10 @@ static int interior_point(const kmpc_params *p, const kmpc_problem *q, double re
     const int N = p->N;
     const double frac = 0.6, T = 1.0, r = p->L_b / (p->L_a + p->L_b);
     memset(Uf, 0, (size_t)2 * N * sizeof(double));
+    /* Q5: the reference bounds v[1], which is pinned to v0 (:67, :113) -- any v0 outside [v_min, v_max] (relaxed like every bound)
+       makes its NLP infeasible, even where a first input could bring v_2 back inside */
+    if (!(q->z0[3] >= p->v_min - relax * fmax(1.0, fabs(p->v_min)) && q->z0[3] <= p->v_max + relax * fmax(1.0, fabs(p->v_max))))
+        return KMPC_INFEASIBLE;
     double len = 0.0;
     /* reference points 1..N only: point 0 is a dead input of the reference NLP (Q3) and must stay one here */
     if (p->model == 0)

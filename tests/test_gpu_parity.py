@@ -134,6 +134,30 @@ def test_infeasible_and_edge_inputs():
     assert o["u0"].shape == (0, 2)  # empty batch is a no-op
 
 
+@pytest.mark.parametrize("N", [8, 20, 13])
+def test_bad_inputs_are_contained(oracle, N):
+    """NaN / Inf / out-of-range inputs in some problems of a batch: those problems report Infeasible (2) or Error (3) -- as the oracle
+    does -- with finite commands inside the input box (the reference node publishes whatever it gets, mpc_cmd_pub.jl:121-132), and
+    every other problem of the launch is bit-identical to the clean launch.  v0 exactly on a bound is fine, a hair outside is not (Q5)."""
+    from mkz_mpc_path_follower_amd import BatchMPC
+    O = oracle
+    d = make_batch(64, N, cfg_id=3)
+    s = BatchMPC(N=N)
+    base = {k: v.cpu().numpy() for k, v in s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"], want_U=True).items()}
+    e = {k: v.copy() for k, v in d.items()}
+    e["z0"][1, 0] = np.nan; e["z0"][2, 3] = np.inf; e["ref"][3, 4, 1] = np.nan; e["v_target"][4] = np.nan; e["u_prev"][5, 0] = np.nan
+    e["u_prev"][6] = (1.5, 0.0); e["u_prev"][7] = (0.0, 0.9); e["z0"][8, 3] = 0.0; e["z0"][9, 3] = 20.0
+    e["z0"][10, 3] = -1e-3; e["z0"][11, 3] = 20.0 + 1e-3
+    r = {k: v.cpu().numpy() for k, v in s.solve(e["z0"], e["ref"], e["v_target"], e["u_prev"], want_U=True).items()}
+    assert list(r["status"][:12]) == [0, 3, 2, 3, 3, 3, 2, 2, 0, 0, 2, 2]
+    assert np.isfinite(r["u0"]).all() and np.isfinite(r["U"]).all()
+    assert np.abs(r["U"][..., 0]).max() <= 1.0 + 1e-8 and np.abs(r["U"][..., 1]).max() <= 0.5 + 1e-8
+    for k in ("u0", "cost", "status", "iters", "U"):
+        assert np.array_equal(base[k][12:], r[k][12:]), k
+    ro = O.solve_condensed_batch(O.params(N), e["z0"][6:12], e["ref"][6:12], e["v_target"][6:12], e["u_prev"][6:12])
+    assert list(ro["status"]) == [2, 2, 0, 0, 2, 2]
+
+
 def test_warm_start_and_host_entry(oracle):
     from mkz_mpc_path_follower_amd import BatchMPC
     from mkz_mpc_path_follower_amd.solver import solve_host
