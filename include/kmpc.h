@@ -66,8 +66,8 @@ typedef struct kmpc_config {
     double tol;          /* Ipopt tol (scaled optimality error), 1e-8 */
     double mu_init;      /* Ipopt mu_init, 0.1 */
     double bound_relax;  /* Ipopt bound_relax_factor, 1e-8 */
-    double warm_push;    /* weight of the interior point blended into a warm start */
-    double warm_mu;      /* mu_init used with a warm start */
+    double warm_push;    /* weight of the interior point blended into a warm start (default 1e-4) */
+    double warm_mu;      /* mu_init used with a warm start (default 1e-6) */
     int32_t max_ls;      /* back-tracking trial points per iteration */
     int32_t kernel_variant; /* 0 = auto (compile-time-horizon kernel when one is built for N, else generic), 1 = generic */
     int32_t mu_strategy;    /* barrier update: 0 = Ipopt's default monotone (Fiacco-McCormick), 1 = Mehrotra predictor-corrector

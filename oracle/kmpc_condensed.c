@@ -16,8 +16,8 @@ void kmpc_opts_default(kmpc_opts *o)
     o->mu_init = 0.1;
     o->bound_relax = 1e-8;
     o->warm = 0;
-    o->warm_push = 0.01;
-    o->warm_mu = 1e-3;
+    o->warm_push = 1e-4;
+    o->warm_mu = 1e-6;
     o->max_ls = 40;
     o->mu_strategy = -1;
     o->indef_strategy = -1;
