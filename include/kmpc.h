@@ -64,7 +64,7 @@ typedef struct kmpc_config {
     int32_t max_iter;    /* cap on linearise+factor iterations (deterministic stand-in for max_cpu_time) */
     int32_t hessian;     /* 0 Gauss-Newton, 1 exact condensed Hessian with GN fallback */
     double tol;          /* Ipopt tol (scaled optimality error), 1e-8 */
-    double mu_init;      /* Ipopt mu_init, 0.1 */
+    double mu_init;      /* barrier parameter of a cold start (default 1.0; Ipopt's is 0.1) */
     double bound_relax;  /* Ipopt bound_relax_factor, 1e-8 */
     double warm_push;    /* weight of the interior point blended into a warm start (default 1e-4) */
     double warm_mu;      /* mu_init used with a warm start (default 1e-6) */

@@ -82,7 +82,7 @@ extern "C" int32_t kmpc_config_default(kmpc_config *c, int32_t N, int32_t dtype)
     c->max_iter = 200;
     c->hessian = 1;
     c->tol = dtype == KMPC_F32 ? 1e-4 : 1e-8;
-    c->mu_init = 0.1;
+    c->mu_init = 1.0;  // Ipopt default is 0.1; with the objective scaled to max-gradient 100, mu = 1 centres the first iterates better (mean iterations -5 %, thinner tail)
     c->bound_relax = dtype == KMPC_F32 ? 1e-5 : 1e-8;
     c->warm_push = 1e-4;  // (1e-4, 1e-6): 25 % fewer iterations from a good warm point than (1e-2, 1e-3), still all Optimal from a wrong one (tools/warm_probe.py)
     c->warm_mu = 1e-6;

@@ -32,7 +32,7 @@ struct KDbg {
     T *H, *g, *J;
 };
 
-constexpr int KMPC_STG = 16;  // scalars stored per stage in LDS
+constexpr int KMPC_STG = 36;  // scalars stored per stage in LDS (Cartesian: 13; Frenet: 13 Jacobian + 3 roll-out + 4 costate + 15 Hessian)
 
 // LDS bytes the solver kernel needs for horizon N with NT column tiles
 template <typename T>

@@ -722,7 +722,8 @@ template <typename T, int N> struct FastSolver {
         bool use_exact = exact;
         enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3, RESTEP = 4 };
         const bool pc = P.mu_strategy == 1;
-        bool corr_active = false, first_attempt = true;
+        bool corr_active = false, first_attempt = true, tiny_stop = false;
+        int n_tiny = 0;
 #pragma unroll
         for (int i = 0; i < NF; ++i) cub[lane + 64 * i] = clb[lane + 64 * i] = (T)0;
         int mode = FIRST;
@@ -759,7 +760,7 @@ template <typename T, int N> struct FastSolver {
 #pragma nounroll
         for (;;) {
             asm volatile("" : "+v"(lane));
-            if (mode == FINAL && have_best && !(status == 0 && cs[C_ERR] <= tol)) {
+            if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && cs[C_ERR] <= tol)) {
                 // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
                 Ut = ubest[lane]; U = Ut; status = 0;
             }
@@ -787,6 +788,13 @@ template <typename T, int N> struct FastSolver {
                     alpha *= (T)0.5;
                     Ut = U + alpha * du;
                     continue;
+                }
+                // Ipopt's tiny-step rule: two accepted steps in a row below 10 eps relative to the iterate -> the arithmetic cannot improve
+                // it; Optimal if the error is within 1e3 tol (where the rounding floor of the fp32 dual residual sits), else Error
+                {
+                    const T stepn = dpp_max(fabs(alpha * du)), umax = fmax((T)1, dpp_max(fabs(U)));
+                    n_tiny = stepn <= (T)10 * Real<T>::eps() * umax ? n_tiny + 1 : 0;
+                    if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= (T)1e3 * tol ? 0 : 3; tiny_stop = true; mode = FINAL; continue; }
                 }
                 // accepted: dual step from the pre-step slacks, then the slacks advance with the step
                 const T ad = cs[C_AD];
@@ -1014,6 +1022,14 @@ template <typename T, int N> struct FastSolver {
         }
         STAMP(11);
         STAMP_OUT(io.stamps, b);
+#ifdef KMPC_STAMPS
+        // diagnostic build only: final optimality error, barrier parameter and last step length in the stamp slots 13..15
+        if (io.stamps && lane == 0) {
+            io.stamps[(size_t)b * 16 + 13] = (unsigned long long)__double_as_longlong((double)cs[C_ERR]);
+            io.stamps[(size_t)b * 16 + 14] = (unsigned long long)__double_as_longlong((double)mu);
+            io.stamps[(size_t)b * 16 + 15] = (unsigned long long)__double_as_longlong((double)alpha);
+        }
+#endif
         if (lane == 0) {
             io.status[b] = status;
             if (io.cost) io.cost[b] = Jt;

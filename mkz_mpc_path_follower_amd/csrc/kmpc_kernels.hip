@@ -237,7 +237,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
     // ---- (b) costates, gradient (n-vector g) and per-stage scalars for the condensing loop -------
     DEV void linearize(const Stage<T> &S, bool exact, T (&g)[NV])
     {
-        if (MODEL == 1) { linearize_frenet(S, g); return; }
+        if (MODEL == 1) { linearize_frenet(S, exact, g); return; }
         const int k = lane;
         const bool st = k < N;
         const T lx = (T)2 * Cx * S.ex, ly = (T)2 * Cy * S.ey, lp = (T)2 * Cp * S.ep, lv = (T)2 * Cv * S.ev;
@@ -300,7 +300,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
     }
     DEV void condense(bool exact, acc_t (&acc)[NACC])
     {
-        if constexpr (MODEL == 1) { condense_dense(acc); return; }
+        if constexpr (MODEL == 1) { condense_dense(exact, acc); return; }
         const int kk = lane >> 4, c = lane & 15;
         if constexpr (LDSACC) {
             for (int e = lane; e < 16 * NT * ld; e += 64) Km[e] = (T)0;
@@ -413,7 +413,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         S.sinb = rr_ * sd * rs;  // sin(atan(r tan d))   (:113)
         S.cosb = cd * rs;
         S.b1 = rr_ / Dn;         // d beta / d d_f
-        S.b2 = (T)0;
+        S.b2 = rr_ * ((T)1 - rr_ * rr_) * ((T)2 * sd * cd) / (Dn * Dn);  // d2 beta / d d_f2
         if (st) { T *q = stg + KMPC_STG * k; q[13] = a; q[14] = S.sinb; q[15] = S.cosb; }  // slots 0..12 hold the stage Jacobians
         WSYNC();
         T s_ = x0, ey_ = y0, ep_ = psi0, v_ = v0;
@@ -448,7 +448,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
     }
 
     // stage record of the Frenet functor: A00 A01 A02 A03 A12 A13 A20 A21 A22 A23 Bs Bey Bep  (A11 = A33 = 1, B_v,acc = dt)
-    DEV void linearize_frenet(const Stage<T> &S, T (&g)[NV])
+    DEV void linearize_frenet(const Stage<T> &S, bool exact, T (&g)[NV])
     {
         const int k = lane;
         const bool st = k < N;
@@ -467,6 +467,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         }
         WSYNC();
         T l0 = wb[4 * N], l1 = wb[4 * N + 1], l2 = wb[4 * N + 2], l3 = wb[4 * N + 3];  // costate of state N
+        if (lane == 0) { T *ql = stg + KMPC_STG * N + 16; ql[0] = l0; ql[1] = l1; ql[2] = l2; ql[3] = l3; }
         for (int kk = N - 1; kk >= 0; --kk) {
             const T *q = stg + KMPC_STG * kk;
             if (lane == 0) { xb[2 * kk] = dt * l3; xb[2 * kk + 1] = q[10] * l0 + q[11] * l1 + q[12] * l2; }  // B_k^T lambda_{k+1}
@@ -476,6 +477,37 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
             const T t3 = q[3] * l0 + q[5] * l1 + q[9] * l2 + l3;
             const T *l = wb + 4 * kk;
             l0 = t0 + l[0]; l1 = t1 + l[1]; l2 = t2 + l[2]; l3 = t3 + l[3];  // (unused after kk = 0)
+            if (lane == 0) { T *ql = stg + KMPC_STG * kk + 16; ql[0] = l0; ql[1] = l1; ql[2] = l2; ql[3] = l3; }
+        }
+        WSYNC();
+        if (exact && st) {
+            // second derivatives of the Euler step wrt (s, e_y, e_psi, v, d_f), contracted with the costate of state k+1 (slots 16..18
+            // of the next record): M = dt [ (l0 - l2 K) Hess(g) - l2 (grad g grad K^T + grad K grad g^T) - l2 g K'' e_s e_s^T
+            //                              + l1 Hess(v sin phi) + l2 Hess(v sin(beta) / L_b) ],  g = ds/dt = v cos(phi) D
+            const T *ln = stg + KMPC_STG * (k + 1) + 16;
+            const T m0 = ln[0], m1 = ln[1], m2 = ln[2];
+            const T s_ = S.x, ey = S.y, v = S.v, C = S.c, Sn = S.s, K = S.K, K1 = S.Kp, K2 = (T)6 * kp0 * s_ + (T)2 * kp1;
+            const T D = S.iden, b1 = S.b1, b2 = S.b2, gq = S.dsdt;
+            const T Ds = ey * K1 * D * D, De = K * D * D;
+            const T Dss = ey * K2 * D * D + (T)2 * ey * K1 * D * Ds, Dse = K1 * D * D + (T)2 * ey * K1 * D * De, Dee = (T)2 * K * D * De;
+            const T g_s = v * C * Ds, g_e = v * C * De, g_p = -v * Sn * D, g_v = C * D, g_d = -v * Sn * b1 * D;
+            const T w = m0 - m2 * K, a2 = m2 * K1;
+            T *q = stg + KMPC_STG * k + 20;  // upper triangle, row-major: ss se sp sv sd | ee ep ev ed | pp pv pd | vv vd | dd
+            q[0] = dt * (w * (v * C * Dss) - (T)2 * a2 * g_s - m2 * gq * K2);
+            q[1] = dt * (w * (v * C * Dse) - a2 * g_e);
+            q[2] = dt * (w * (-v * Sn * Ds) - a2 * g_p);
+            q[3] = dt * (w * (C * Ds) - a2 * g_v);
+            q[4] = dt * (w * (-v * Sn * b1 * Ds) - a2 * g_d);
+            q[5] = dt * (w * (v * C * Dee));
+            q[6] = dt * (w * (-v * Sn * De));
+            q[7] = dt * (w * (C * De));
+            q[8] = dt * (w * (-v * Sn * b1 * De));
+            q[9] = dt * (w * (-v * C * D) + m1 * (-v * Sn));
+            q[10] = dt * (w * (-Sn * D) + m1 * C);
+            q[11] = dt * (w * (-v * C * b1 * D) + m1 * (-v * Sn * b1));
+            q[12] = (T)0;
+            q[13] = dt * (w * (-Sn * b1 * D) + m1 * (C * b1) + m2 * (S.cosb * b1 / Lb));
+            q[14] = dt * (w * (v * D * (-C * b1 * b1 - Sn * b2)) + m1 * (v * (-Sn * b1 * b1 + C * b2)) + m2 * (v * (-S.sinb * b1 * b1 + S.cosb * b2) / Lb));
         }
         WSYNC();
         // input-cost terms, Frenet.jl:99-102 (same as the Cartesian model)
@@ -493,9 +525,10 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         WSYNC();
     }
 
-    // Gauss-Newton condensing with dense stage Jacobians: every lane keeps all four components of G for its column of each tile
-    // (replicated over the four kk groups); the MFMA fragment is component kk.
-    DEV void condense_dense(acc_t (&acc)[NACC])
+    // Condensing with dense stage Jacobians: every lane keeps all four components of G for its column of each tile (replicated over
+    // the four kk groups); the MFMA fragment is component kk.  exact: + the second-order term (5x5 stage blocks M of linearize_frenet):
+    // its state part joins the weights of the contraction, its d_f row is added to row 2s+1 of the tiles.
+    DEV void condense_dense(bool exact, acc_t (&acc)[NACC])
     {
         static_assert(!(MODEL == 1 && LDSACC), "the Frenet functor keeps its tiles in registers (NT <= 4)");
         const int kk = lane >> 4, c = lane & 15;
@@ -504,33 +537,65 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         T g0[NT], g1[NT], g2[NT], g3[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) g0[t] = g1[t] = g2[t] = g3[t] = (T)0;
-        for (int s = 1; s <= N; ++s) {  // G_s = [A_{s-1} G_{s-1} | B_{s-1}]
-            const T *q = stg + KMPC_STG * (s - 1);
-            const T A00 = q[0], A01 = q[1], A02 = q[2], A03 = q[3], A12 = q[4], A13 = q[5], A20 = q[6], A21 = q[7], A22 = q[8], A23 = q[9];
-            const T Bs = q[10], Bey = q[11], Bep = q[12];
-            const int col0 = 2 * (s - 1);
-            const T Cvs = s <= N - 1 ? Cv : (T)0;
-            const T dco = kk == 0 ? (T)2 * Cx : (kk == 1 ? (T)2 * Cy : (kk == 2 ? (T)2 * Cp : (T)2 * Cvs));
-            T own[NT], bop[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const T n0 = A00 * g0[t] + A01 * g1[t] + A02 * g2[t] + A03 * g3[t];
-                const T n1 = g1[t] + A12 * g2[t] + A13 * g3[t];
-                const T n2 = A20 * g0[t] + A21 * g1[t] + A22 * g2[t] + A23 * g3[t];
-                g0[t] = n0; g1[t] = n1; g2[t] = n2;
-                const int col = 16 * t + c;
-                if (col == col0) { g0[t] = (T)0; g1[t] = (T)0; g2[t] = (T)0; g3[t] = dt; }
-                if (col == col0 + 1) { g0[t] = Bs; g1[t] = Bey; g2[t] = Bep; g3[t] = (T)0; }
-                own[t] = kk == 0 ? g0[t] : (kk == 1 ? g1[t] : (kk == 2 ? g2[t] : g3[t]));
-                bop[t] = dco * own[t];
-            }
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti)
-                if (16 * ti < 2 * s) {
-#pragma unroll
-                    for (int tj = 0; tj <= ti; ++tj)
-                        acc[LDSACC ? 0 : ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[LDSACC ? 0 : ti * (ti + 1) / 2 + tj]);
+        for (int s = 0; s <= N; ++s) {
+            if (s >= 1) {  // G_s = [A_{s-1} G_{s-1} | B_{s-1}]
+                const T *q = stg + KMPC_STG * (s - 1);
+                const T A00 = q[0], A01 = q[1], A02 = q[2], A03 = q[3], A12 = q[4], A13 = q[5], A20 = q[6], A21 = q[7], A22 = q[8], A23 = q[9];
+                const T Bs = q[10], Bey = q[11], Bep = q[12];
+                const int col0 = 2 * (s - 1);
+                const T Cvs = s <= N - 1 ? Cv : (T)0;
+                // row kk of the weight 2 Q_s + M_s^{zz}
+                T w0 = kk == 0 ? (T)2 * Cx : (T)0, w1 = kk == 1 ? (T)2 * Cy : (T)0, w2 = kk == 2 ? (T)2 * Cp : (T)0, w3 = kk == 3 ? (T)2 * Cvs : (T)0;
+                if (exact && s < N) {
+                    const T *m = stg + KMPC_STG * s + 20;
+                    w0 += kk == 0 ? m[0] : (kk == 1 ? m[1] : (kk == 2 ? m[2] : m[3]));
+                    w1 += kk == 0 ? m[1] : (kk == 1 ? m[5] : (kk == 2 ? m[6] : m[7]));
+                    w2 += kk == 0 ? m[2] : (kk == 1 ? m[6] : (kk == 2 ? m[9] : m[10]));
+                    w3 += kk == 0 ? m[3] : (kk == 1 ? m[7] : (kk == 2 ? m[10] : m[12]));
                 }
+                T own[NT], bop[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const T n0 = A00 * g0[t] + A01 * g1[t] + A02 * g2[t] + A03 * g3[t];
+                    const T n1 = g1[t] + A12 * g2[t] + A13 * g3[t];
+                    const T n2 = A20 * g0[t] + A21 * g1[t] + A22 * g2[t] + A23 * g3[t];
+                    g0[t] = n0; g1[t] = n1; g2[t] = n2;
+                    const int col = 16 * t + c;
+                    if (col == col0) { g0[t] = (T)0; g1[t] = (T)0; g2[t] = (T)0; g3[t] = dt; }
+                    if (col == col0 + 1) { g0[t] = Bs; g1[t] = Bey; g2[t] = Bep; g3[t] = (T)0; }
+                    own[t] = kk == 0 ? g0[t] : (kk == 1 ? g1[t] : (kk == 2 ? g2[t] : g3[t]));
+                    bop[t] = w0 * g0[t] + w1 * g1[t] + w2 * g2[t] + w3 * g3[t];
+                }
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+                    if (16 * ti < 2 * s) {
+#pragma unroll
+                        for (int tj = 0; tj <= ti; ++tj)
+                            acc[LDSACC ? 0 : ti * (ti + 1) / 2 + tj] = Real<T>::mfma(own[ti], bop[tj], acc[LDSACC ? 0 : ti * (ti + 1) / 2 + tj]);
+                    }
+            }
+            if (exact && s < N) {  // row 2s+1 (d_f of stage s): M^{z d}^T G_s, M^{dd} on the diagonal
+                const T *m = stg + KMPC_STG * s + 20;
+                const T msd = m[4], med = m[8], mpd = m[11], mvd = m[13], mdd = m[14];
+                const int rho = 2 * s + 1, rt = rho >> 4, rr = rho & 15;
+                const bool mine = kk == Real<T>::q_of_row(rr);
+                const int reg = Real<T>::reg_of_row(rr);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+                    if (ti == rt) {
+#pragma unroll
+                        for (int tj = 0; tj <= ti; ++tj) {
+                            T val = msd * g0[tj] + med * g1[tj] + mpd * g2[tj] + mvd * g3[tj];
+                            if (tj == ti && c == rr) val += mdd;
+                            if (!mine) val = (T)0;
+                            acc_t &A = acc[LDSACC ? 0 : ti * (ti + 1) / 2 + tj];
+                            A[0] += reg == 0 ? val : (T)0;
+                            A[1] += reg == 1 ? val : (T)0;
+                            A[2] += reg == 2 ? val : (T)0;
+                            A[3] += reg == 3 ? val : (T)0;
+                        }
+                    }
+            }
         }
     }
 
@@ -745,13 +810,14 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         const T kappa_eps = 10, kappa_mu = (T)0.2, theta_mu = (T)1.5, tau_min = (T)0.99, kappa_sigma = (T)1e10,
                 eta_phi = (T)1e-8, s_max = 100;
         const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
-        const bool exact = P.hessian == 1 && MODEL == 0;  // the Frenet functor is Gauss-Newton only
+        const bool exact = P.hessian == 1;
         T U[NV], Uf[NV], g[NV], du[NV], rhs[NV], Ut[NV];
         T bu[NF], bl[NF], rlx[NF], su[NF], sl[NF], lu[NF], ll[NF], au[NF], aut[NF], dlu[NF], dll[NF], w[NF];
         bool fv[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i], rlx[i]); }
-        int status = 1, iters = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
+        int status = 1, iters = 0, n_polish = 0, n_accept = 0, gn_hold = 0, n_tiny = 0;
+        bool tiny_stop = false;
         T dw_last = 0, dw_spec = 0, hmax = 0;
         int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
         bool have_best = false;
@@ -1012,9 +1078,17 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                 }
                 STAMP(9);
                 if (!accepted) { status = err0 <= (T)100 * tol ? 0 : 3; break; }  // acceptable level reached
+                {   // Ipopt's tiny-step rule (see the oracle): two accepted steps in a row below 10 eps relative to the iterate
+                    T sm = 0, um = 1;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) { sm = fmax(sm, fabs(alpha_acc * du[i])); um = fmax(um, fabs(U[i])); }
+                    sm = wave_max(sm); um = wave_max(um);
+                    n_tiny = sm <= (T)10 * Real<T>::eps() * um ? n_tiny + 1 : 0;
+                }
 #pragma unroll
                 for (int i = 0; i < NV; ++i) U[i] = Ut[i];
                 J = Jt;
+                if (n_tiny >= 2) { status = err0 <= (T)1e3 * tol ? 0 : 3; tiny_stop = true; break; }
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
@@ -1027,7 +1101,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         }
         STAMP(10);
         // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
-        if (have_best && !(status == 0 && err0 <= tol)) {
+        if (have_best && !tiny_stop && !(status == 0 && err0 <= tol)) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) U[i] = Ubest[i];
             status = 0;

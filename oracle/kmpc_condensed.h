@@ -28,7 +28,7 @@ typedef struct kmpc_opts {
     int max_iter;        /* outer (linearise + factor) iterations */
     double tol;          /* Ipopt tol on the scaled optimality error (1e-8) */
     int hessian;         /* 0 = Gauss-Newton, 1 = exact (falls back to GN when not PD) */
-    double mu_init;      /* Ipopt mu_init = 0.1 */
+    double mu_init;      /* cold-start barrier parameter (1.0; Ipopt's default is 0.1) */
     double bound_relax;  /* Ipopt bound_relax_factor = 1e-8 */
     int warm;            /* 1: U on entry is a warm start (blended into the interior) */
     double warm_push;    /* weight of the analytic interior point in the blend (0.01) */

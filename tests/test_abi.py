@@ -34,7 +34,8 @@ def test_config_defaults_are_the_reference_constants():
     assert L.kmpc_config_default(C.byref(c), 8, _lib.KMPC_F64) == 0
     assert (c.N, c.dt, c.dt_control, c.L_a, c.L_b) == (8, 0.20, 0.10, 1.108, 1.742)
     assert (c.steer_max, c.steer_dmax, c.a_max, c.a_dmax, c.v_min, c.v_max) == (0.5, 0.5, 1.0, 1.5, 0.0, 20.0)
-    assert c.tol == 1e-8 and c.mu_init == 0.1 and c.bound_relax == 1e-8  # Ipopt defaults
+    assert c.tol == 1e-8 and c.bound_relax == 1e-8  # Ipopt defaults
+    assert c.mu_init == 1.0  # deliberately not Ipopt's 0.1
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_config():

@@ -8,10 +8,12 @@ FRENET_W = (0.0, 9.0, 10.0, 0.5, 100.0, 1000.0, 0.0, 0.0)  # MKZMPCPathFollowerF
 
 
 def _cases(B, N, seed=3):
-    """(s0, e_y0, e_psi0, v0), cubic curvature polynomials with |K| <= ~0.08 over the horizon, target speeds, previous inputs"""
+    """(s0, e_y0, e_psi0, v0); cubic curvature polynomials K(s) = a + b x + c x^2 + d x^3, x = s / 60 m, that stay within road-like
+    curvature (|K| <~ 0.09 1/m, the range of the recorded paths) over any horizon used here; target speeds; previous inputs"""
     rng = np.random.default_rng(seed)
     z0 = np.stack([rng.uniform(0, 5, B), rng.normal(0, 0.4, B), rng.normal(0, 0.08, B), rng.uniform(2, 12, B)], 1)
-    kp = np.stack([rng.normal(0, 2e-6, B), rng.normal(0, 1e-4, B), rng.normal(0, 2e-3, B), rng.uniform(-0.06, 0.06, B)], 1)
+    a, b, c, d = rng.uniform(-0.04, 0.04, B), rng.normal(0, 0.015, B), rng.normal(0, 0.015, B), rng.normal(0, 0.015, B)
+    kp = np.stack([d / 60.0 ** 3, c / 60.0 ** 2, b / 60.0, a], 1)  # highest degree first
     vt = np.clip(z0[:, 3] + rng.normal(0, 1.0, B), 1.0, 15.0)
     up = np.stack([rng.uniform(-0.4, 0.4, B), rng.uniform(-0.05, 0.05, B)], 1)
     return z0, kp, vt, up
