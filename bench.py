@@ -73,22 +73,75 @@ def closed_loop_latency(device, steps=150):
             "worst_status": worst}
 
 
+def parity_sample(N, d, out, ro, tol=1e-6):
+    """GPU vs the CPU port on the sampled problems.  The NLP is non-convex: on a few problems per thousand whose Hessian is
+    indefinite along the way, rounding-level differences between the two implementations end in different local minima; those
+    are counted separately and both solutions are checked to be KKT points (least-squares multipliers on the active set)."""
+    from oracle import oracle as O
+    S = ro["cost"].shape[0]
+    gc = out["cost"][:S].double().cpu().numpy()
+    rel = np.abs(gc - ro["cost"]) / np.maximum(1.0, np.abs(ro["cost"]))
+    within = rel <= tol
+    info = {"n": int(S), "tol": tol, "within_tol": int(within.sum()), "max_rel_cost_err_within_tol": float(rel[within].max()) if within.any() else None,
+            "max_viol": float(out["viol"].max().item()), "other_local_minimum": 0, "unexplained": 0}
+    bad = np.where(~within)[0]
+    if len(bad) and "U" in out:
+        p = O.params(N)
+        gU = out["U"][:S].double().cpu().numpy()
+        for b in bad[:32]:
+            q = O.problem(p, d["z0"][b], d["ref"][b], d["v_target"][b], d["u_prev"][b])
+            A, bb = O.ineq(p, q)
+            kkt = []
+            for U in (gU[b], ro["U"][b]):
+                gr = O.grad(p, q, U)
+                act = (bb - A @ U.ravel()) < 1e-6
+                lam = np.linalg.lstsq(A[act].T, -gr, rcond=None)[0] if act.any() else np.zeros(0)
+                r_ = gr + (A[act].T @ lam if act.any() else 0.0)
+                kkt.append(np.abs(r_).max() <= 1e-4 * max(1.0, np.abs(gr).max()) and (lam.min() if act.any() else 0.0) >= -1e-4 * max(1.0, np.abs(gr).max()))
+            info["other_local_minimum" if all(kkt) else "unexplained"] += 1
+        info["max_rel_cost_err_other_minimum"] = float(rel[bad].max())
+    return info
+
+
+def host_cores():
+    """threads worth starting: the affinity mask, capped by the cgroup CPU quota when there is one (a 1-GPU box exposes 256 logical
+    CPUs but grants a share of them)"""
+    n = len(os.sched_getaffinity(0))
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if t[0] != "max":
+                    n = min(n, max(1, int(np.ceil(float(t[0]) / float(t[1])))))
+            else:
+                q = float(t[0]); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(np.ceil(q / per))))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(N, d, budget_s=15.0):
     """oracle/ CPU port (same algorithm, scalar C, pthreads over problems) on a bounded sample."""
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     p = O.params(N)
     pilot = min(4 * cores, d["z0"].shape[0])
     t = time.perf_counter()
     O.solve_condensed_batch(p, d["z0"][:pilot], d["ref"][:pilot], d["v_target"][:pilot], d["u_prev"][:pilot], nthreads=cores)
     rate = pilot / max(time.perf_counter() - t, 1e-9)
     S = int(min(d["z0"].shape[0], max(pilot, rate * budget_s)))
-    t = time.perf_counter()
-    r = O.solve_condensed_batch(p, d["z0"][:S], d["ref"][:S], d["v_target"][:S], d["u_prev"][:S], nthreads=cores)
-    el = time.perf_counter() - t
-    return dict(value=S / el, unit="solves/s", cores=cores, kind="port",
-                sample="first %d of the %d-problem GPU batch, oracle/kmpc_condensed.c (scalar fp64 C, %d pthreads), "
-                       "mean %.1f iterations" % (S, d["z0"].shape[0], cores, float(r["iters"].mean()))), r
+    el, reps = 0.0, 0
+    while el < 3.0 and reps < 64:  # the sample is a fraction of a second on a many-core host: repeat it for a stable figure
+        t = time.perf_counter()
+        r = O.solve_condensed_batch(p, d["z0"][:S], d["ref"][:S], d["v_target"][:S], d["u_prev"][:S], nthreads=cores)
+        el += time.perf_counter() - t
+        reps += 1
+    return dict(value=S * reps / el, unit="solves/s", cores=cores, kind="port",
+                sample="first %d of the %d-problem GPU batch x %d repeats, oracle/kmpc_condensed.c (scalar fp64 C, %d pthreads), "
+                       "mean %.1f iterations" % (S, d["z0"].shape[0], reps, cores, float(r["iters"].mean()))), r
 
 
 def main():
@@ -197,11 +250,10 @@ def main():
             if not a.no_cpu_baseline:
                 cb, ro = cpu_baseline(N, d)
                 res["cpu_baseline"] = cb
+                out = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], want_U=True)  # untimed, with the input trajectories
+                torch.cuda.synchronize()
                 # parity spot check of the timed batch against the CPU port on the sampled problems
-                S = ro["cost"].shape[0]
-                gc = out["cost"][:S].double().cpu().numpy()
-                res["parity_sample"] = {"n": S, "max_rel_cost_err": float(np.max(np.abs(gc - ro["cost"]) / np.maximum(1.0, np.abs(ro["cost"])))),
-                                        "max_viol": float(out["viol"].max().item())}
+                res["parity_sample"] = parity_sample(N, d, out, ro)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
