@@ -315,7 +315,7 @@ template <typename T, int N> struct FastSolver {
         }
         {
             T *q = lin + LIN_STRIDE * (k <= N ? k : N);
-            T *dmy = xb + 48;  // lanes > N write nowhere that matters
+            T *dmy = xb + 62;  // lanes > N write past the n <= 56 gradient entries held in xb
             T *w0 = k <= N ? q : dmy;
             w0[0] = A02; w0[1] = A03;
             if (k <= N) { q[2] = A12; q[3] = A13; q[4] = A23; q[5] = Bdx; q[6] = Bdy; q[7] = Bdp;
@@ -411,7 +411,8 @@ template <typename T, int N> struct FastSolver {
         condense_trips<0>(0, 1, S, acc, sc, exs);
         condense_trips<1>(1, N < 9 ? N : 9, S, acc, sc, exs);
         if (NT >= 2 && N > 9) condense_trips<(NT >= 2 ? 2 : 1)>(9, N < 17 ? N : 17, S, acc, sc, exs);
-        if (NT >= 3 && N > 17) condense_trips<(NT >= 3 ? 3 : 1)>(17, N, S, acc, sc, exs);
+        if (NT >= 3 && N > 17) condense_trips<(NT >= 3 ? 3 : 1)>(17, N < 25 ? N : 25, S, acc, sc, exs);
+        if (NT >= 4 && N > 25) condense_trips<(NT >= 4 ? 4 : 1)>(25, N, S, acc, sc, exs);
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -580,7 +581,8 @@ template <typename T, int N> struct FastSolver {
         STAMP(12);
         if (NTF > 1 && n > 16) { if (ok) ok = chol_blocks<(NTF > 1 ? 1 : 0)>(kt, 4, (n < 32 ? n : 32) / 4); }
         STAMP(13);
-        if (NTF > 2 && n > 32) { if (ok) ok = chol_blocks<(NTF > 2 ? 2 : 0)>(kt, 8, n / 4); }
+        if (NTF > 2 && n > 32) { if (ok) ok = chol_blocks<(NTF > 2 ? 2 : 0)>(kt, 8, (n < 48 ? n : 48) / 4); }
+        if (NTF > 3 && n > 48) { if (ok) ok = chol_blocks<(NTF > 3 ? 3 : 0)>(kt, 12, n / 4); }
         STAMP(14);
         if (!ok) return false;
         WFENCE();
@@ -833,7 +835,6 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
                         if (fv[i]) {
-                            const T su = sup[i], sl = slo[i];
                             lu[i] = fmax(fmin(lu[i], kappa_sigma * mu * isu[i]), mu * isu[i] / kappa_sigma);
                             ll[i] = fmax(fmin(ll[i], kappa_sigma * mu * isl[i]), mu * isl[i] / kappa_sigma);
                         }
@@ -1061,12 +1062,17 @@ static hipError_t launch_fast_n(const KP &P, const KIO<T> &io, hipStream_t st)
 }
 
 // horizons with a compiled fast kernel; everything else runs the generic kernel
-template <typename T> bool kmpc_fast_available(int N) { return N == 8 || N == 20; }  // 3N + 1 <= 63
+// compile-time horizons: N % 4 == 0 and 2N + 1 <= 64
+template <typename T> bool kmpc_fast_available(int N) { return N == 8 || N == 12 || N == 16 || N == 20 || N == 24 || N == 28; }
 template <typename T> hipError_t kmpc_launch_solve_fast(const KP &P, const KIO<T> &io, hipStream_t st)
 {
     switch (P.N) {
         case 8: return launch_fast_n<T, 8>(P, io, st);
+        case 12: return launch_fast_n<T, 12>(P, io, st);
+        case 16: return launch_fast_n<T, 16>(P, io, st);
         case 20: return launch_fast_n<T, 20>(P, io, st);
+        case 24: return launch_fast_n<T, 24>(P, io, st);
+        case 28: return launch_fast_n<T, 28>(P, io, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -36,8 +36,9 @@ def test_known_answers(oracle, N):
     assert abs(r["cost"][0] - Jstar) < 1e-6 * Jstar
 
 
-@pytest.mark.parametrize("N,B", [(8, 64), (20, 256), (50, 32)])
+@pytest.mark.parametrize("N,B", [(8, 64), (20, 256), (50, 32), (12, 128), (16, 128), (24, 128), (28, 128), (13, 64)])
 def test_batch_matches_oracle_fp64(oracle, N, B):
+    """compile-time-horizon kernel for N in {8, 12, 16, 20, 24, 28}, generic kernel for the rest (13, 50)"""
     O = oracle
     d = make_batch(B, N, cfg_id=2)
     r = _solve(N, d)
@@ -52,6 +53,17 @@ def test_batch_matches_oracle_fp64(oracle, N, B):
     assert np.abs(r["X"] - ro["X"]).max() <= 1e-4
     # iteration counts follow the oracle's (same algorithm, different summation order)
     assert abs(r["iters"].mean() - ro["iters"].mean()) < 1.0
+
+
+@pytest.mark.parametrize("N", [8, 12, 16, 24, 28])
+def test_fast_and_generic_kernels_agree(N):
+    """the two kernels implement the same algorithm: same statuses and costs to 1e-9 relative, iteration counts within rounding effects"""
+    d = make_batch(256, N, cfg_id=6)
+    a = _solve(N, d, kernel_variant=0)
+    b = _solve(N, d, kernel_variant=1)
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    rel = np.abs(a["cost"] - b["cost"]) / np.maximum(1.0, np.abs(b["cost"]))
+    assert rel.max() <= 1e-7 and abs(a["iters"].mean() - b["iters"].mean()) < 0.5
 
 
 def test_batch_fp32(oracle):
