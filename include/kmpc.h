@@ -71,10 +71,10 @@ typedef struct kmpc_config {
     int32_t max_ls;      /* back-tracking trial points per iteration */
     int32_t kernel_variant; /* 0 = auto (compile-time-horizon kernel when one is built for N, else generic), 1 = generic */
     int32_t mu_strategy;    /* barrier update: 0 = Ipopt's default monotone (Fiacco-McCormick), 1 = Mehrotra predictor-corrector
-                               (Ipopt's adaptive family); kmpc_config_default picks 1 for N <= 24, 0 for longer horizons */
+                               (Ipopt's adaptive family; default) */
     int32_t indef_strategy; /* exact Hessian not positive definite: 0 = Gauss-Newton fallback (held for 2 iterations), 1 = Ipopt-style
                                delta_w shift of the exact Hessian, 2 = hybrid (0 until the second failure of a solve, 1 from then on);
-                               kmpc_config_default picks 2 for N <= 24, 1 for longer horizons */
+                               2 is the default */
     int32_t schedule;       /* order in which the problems of a batch start on the GPU: 0 = index order, 1 (default) = longest
                                predicted first (key = |v0 - reference speed| + 1.33 * total heading change of the reference), which
                                shortens the tail of a launch whose time is set by its slowest problems.  Results do not depend on it.

@@ -433,8 +433,8 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
            *au = ll + nf, *dlu = au + nf, *dll = dlu + nf, *w = dll + nf, *aut = w + nf, *w2 = aut + nf;
     double *Xl = w2 + 2 * nf, *Xt = Xl + (N + 1) * 4;
     int status = KMPC_ITERATION_LIMIT, iters = 0, n_refac = 0, n_ls = 0, n_solves = 0;
-    /* barrier strategy: -1 = default by horizon (Mehrotra validated for N <= 24; longer horizons keep Ipopt's monotone rule) */
-    const int mu_strategy = o->mu_strategy >= 0 ? o->mu_strategy : (N <= 24 ? 1 : 0);
+    /* barrier strategy: -1 = default = Mehrotra (validated on seeded draws at N = 8 ... 56 with the safeguards below) */
+    const int mu_strategy = o->mu_strategy >= 0 ? o->mu_strategy : 1;
     double mu = o->warm ? o->warm_mu : o->mu_init, err0 = INFINITY, sc = 1.0, J = 0.0;
     const double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, kappa_sigma = 1e10,
                  eta_phi = 1e-8, s_max = 100.0;
@@ -443,7 +443,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
     int gn_hold = 0;
     double dw_last = 0.0, dw_spec = 0.0, hmax_prev = 0.0;
     /* 2 = hybrid: Gauss-Newton fallback until the exact Hessian has failed gn_switch times, delta_w shift from then on */
-    const int indef_cfg = o->indef_strategy >= 0 ? o->indef_strategy : (N <= 24 ? 2 : 1);
+    const int indef_cfg = o->indef_strategy >= 0 ? o->indef_strategy : 2;
     int indef_strategy = indef_cfg == 2 ? 0 : indef_cfg, n_fail = 0;
     const int gn_switch = 2;
     /* Mehrotra safeguards: the barrier target may not drop below (scaled dual infeasibility)/kappa_rd while that exceeds the

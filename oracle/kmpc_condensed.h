@@ -35,9 +35,9 @@ typedef struct kmpc_opts {
     double warm_mu;      /* mu_init used with a warm start */
     int max_ls;          /* back-tracking steps */
     int mu_strategy;     /* 0 = Ipopt's monotone Fiacco-McCormick default, 1 = Mehrotra predictor-corrector (adaptive),
-                            -1 (default) = by horizon: 1 for N <= 24, 0 for longer horizons */
+                            -1 (default) = 1 */
     int indef_strategy;  /* indefinite exact Hessian: 0 = Gauss-Newton fallback (held 2 iterations), 1 = Ipopt-style delta_w shift,
-                            2 = hybrid (0 until the second failure, then 1), -1 (default) = by horizon: 2 for N <= 24, 1 for longer */
+                            2 = hybrid (0 until the second failure, then 1), -1 (default) = 2 */
 } kmpc_opts;
 
 typedef struct kmpc_result {
