@@ -119,6 +119,32 @@ def test_full_size_batch_properties():
     assert np.allclose(X[:, 1:, 3], X[:, :-1, 3] + 0.2 * U[:, :, 0], atol=1e-12)
 
 
+def test_full_size_rigid_motion_invariance():
+    """Size-independent property at BASELINE configs[1] size: with C_x = C_y (the node's weights) the NLP is invariant under a rigid
+    motion of the plane -- rotate and translate poses and references by a recorded-path-sized offset and the optimal costs and
+    inputs must not change (this is what the vehicle-centred solve buys: 600 m offsets cost no digits)."""
+    N, B = 20, 4096
+    d = make_batch(B, N, cfg_id=7)
+    r = _solve(N, d)
+    th, tx, ty = 0.83, -612.5, 431.25
+    c, s_ = np.cos(th), np.sin(th)
+    m = dict(d)
+    m["z0"] = d["z0"].copy()
+    m["z0"][:, 0] = c * d["z0"][:, 0] - s_ * d["z0"][:, 1] + tx
+    m["z0"][:, 1] = s_ * d["z0"][:, 0] + c * d["z0"][:, 1] + ty
+    m["z0"][:, 2] = d["z0"][:, 2] + th
+    m["ref"] = d["ref"].copy()
+    m["ref"][..., 0] = c * d["ref"][..., 0] - s_ * d["ref"][..., 1] + tx
+    m["ref"][..., 1] = s_ * d["ref"][..., 0] + c * d["ref"][..., 1] + ty
+    m["ref"][..., 2] = d["ref"][..., 2] + th
+    rm = _solve(N, m)
+    assert (r["status"] == 0).all() and (rm["status"] == 0).all()
+    rel = np.abs(r["cost"] - rm["cost"]) / np.maximum(1.0, np.abs(r["cost"]))
+    same = rel <= 1e-6
+    assert same.mean() >= 0.999, (rel.max(), (~same).sum())    # (a negative-curvature problem may land in another local minimum)
+    assert np.abs(r["u0"] - rm["u0"])[same].max() <= 1e-5
+
+
 def test_start_order_does_not_change_results():
     """Longest-predicted-first scheduling (kmpc_config.schedule, kmpc_schedule.hip) only permutes which workgroup
     solves which problem: every output of every problem is bit-identical to the index-order launch, for both kernels."""
