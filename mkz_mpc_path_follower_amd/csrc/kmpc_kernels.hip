@@ -283,26 +283,34 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
 
     // ---- (c) condensing on the matrix cores ------------------------------------------------------
     // acc[tile(ti,tj)] accumulates  sum_s G_s^T (2 Q_s + M_s) G_s  + delta-row terms  (unscaled)
-    // tile (ti, tj) of the tile-padded LDS matrix in MFMA C layout (LDSACC only: the matrix has 16 NT rows, so no bounds checks)
+    // tile (ti, tj) of the tile-padded LDS matrix in MFMA C layout (LDSACC only: the matrix has 16 NT rows, so no bounds checks);
+    // the four per-lane element offsets are computed once (tofs), a tile adds one wave-uniform offset
+    int tofs[4];
+    DEV void tile_init()
+    {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tofs[r] = Real<T>::row_of(lane, r) * ld + (lane & 15);
+    }
     DEV acc_t tile_load(int ti, int tj) const
     {
-        const T *base = Km + (16 * ti) * ld + 16 * tj + (lane & 15);
+        const T *base = Km + (16 * ti) * ld + 16 * tj;
         acc_t a;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = base[Real<T>::row_of(lane, r) * ld];
+        for (int r = 0; r < 4; ++r) a[r] = base[tofs[r]];
         return a;
     }
     DEV void tile_store(int ti, int tj, const acc_t &a)
     {
-        T *base = Km + (16 * ti) * ld + 16 * tj + (lane & 15);
+        T *base = Km + (16 * ti) * ld + 16 * tj;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) base[Real<T>::row_of(lane, r) * ld] = a[r];
+        for (int r = 0; r < 4; ++r) base[tofs[r]] = a[r];
     }
     DEV void condense(bool exact, acc_t (&acc)[NACC])
     {
         if constexpr (MODEL == 1) { condense_dense(exact, acc); return; }
         const int kk = lane >> 4, c = lane & 15;
         if constexpr (LDSACC) {
+            tile_init();
             for (int e = lane; e < 16 * NT * ld; e += 64) Km[e] = (T)0;
             WSYNC();
         } else {
@@ -716,29 +724,49 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         return true;
     }
 
-    // x <- K^{-1} x with the factor in LDS
+    // x <- K^{-1} x with the factor in LDS: forward and backward substitution, one column per step.  The pivot component is
+    // broadcast with v_readlane (wave-uniform column index) and the column entries of the next step are fetched while the current
+    // FMA chain runs -- the version with __shfl (an LDS round trip per column) took 110 k cycles per solve at N = 50.
     DEV void chol_solve(T (&x)[NV])
     {
+        T cn[NV], dn = dinv[0];
+#pragma unroll
+        for (int ii = 0; ii < NV; ++ii) { const int i = lane + 64 * ii; cn[ii] = i < n ? Km[i * ld] : (T)0; }
         for (int j = 0; j < n; ++j) {
-            T xj = __shfl(x[0], j & 63);
-            if (NV > 1) { const T x1 = __shfl(x[NV - 1], j & 63); if (j >= 64) xj = x1; }
-            xj *= dinv[j];
+            T c[NV];
+            const T dj = dn;
+            const int jn = j + 1 < n ? j + 1 : j;
+            dn = dinv[jn];
+#pragma unroll
+            for (int ii = 0; ii < NV; ++ii) { c[ii] = cn[ii]; const int i = lane + 64 * ii; cn[ii] = Km[(i < n ? i : 0) * ld + jn]; }
+            T xj = readlane_(x[0], j & 63);
+            if (NV > 1) { const T x1 = readlane_(x[NV - 1], j & 63); if (j >= 64) xj = x1; }
+            xj *= dj;
 #pragma unroll
             for (int ii = 0; ii < NV; ++ii) {
                 const int i = lane + 64 * ii;
-                if (i == j) x[ii] = xj;
-                else if (i > j && i < n) x[ii] -= Km[i * ld + j] * xj;
+                const T upd = x[ii] - c[ii] * xj;
+                x[ii] = i == j ? xj : ((i > j && i < n) ? upd : x[ii]);
             }
         }
+        dn = dinv[n - 1];
+#pragma unroll
+        for (int ii = 0; ii < NV; ++ii) { const int i = lane + 64 * ii; cn[ii] = Km[(n - 1) * ld + (i < n ? i : 0)]; }
         for (int j = n - 1; j >= 0; --j) {
-            T xj = __shfl(x[0], j & 63);
-            if (NV > 1) { const T x1 = __shfl(x[NV - 1], j & 63); if (j >= 64) xj = x1; }
-            xj *= dinv[j];
+            T c[NV];
+            const T dj = dn;
+            const int jp = j >= 1 ? j - 1 : 0;
+            dn = dinv[jp];
+#pragma unroll
+            for (int ii = 0; ii < NV; ++ii) { c[ii] = cn[ii]; const int i = lane + 64 * ii; cn[ii] = Km[jp * ld + (i < n ? i : 0)]; }
+            T xj = readlane_(x[0], j & 63);
+            if (NV > 1) { const T x1 = readlane_(x[NV - 1], j & 63); if (j >= 64) xj = x1; }
+            xj *= dj;
 #pragma unroll
             for (int ii = 0; ii < NV; ++ii) {
                 const int i = lane + 64 * ii;
-                if (i == j) x[ii] = xj;
-                else if (i < j) x[ii] -= Km[j * ld + i] * xj;
+                const T upd = x[ii] - c[ii] * xj;
+                x[ii] = i == j ? xj : (i < j ? upd : x[ii]);
             }
         }
     }
