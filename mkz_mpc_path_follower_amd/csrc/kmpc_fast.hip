@@ -428,9 +428,7 @@ template <typename T, int N> struct FastSolver {
     // adds afterwards together with the input-cost Hessian (MKZMPCPathFollower.jl:99-102).
     DEV void build_K(const acc_t (&acc)[NTT], T sc, T reg, T rhs)
     {
-        const int c = lane & 15, q = lane >> 4;
-        const bool ee = !((Real<T>::row_of(lane, 0) | c) & 1) && !((Real<T>::row_of(lane, 1)) & 1);  // rows q+4r / 4q+r: parity
-        // (for f64 row = q + 4r: parity of row == parity of q for every r; for f32 row = 4q + r: parity follows r)
+        const int c = lane & 15;
         const T dt2 = dt * dt;
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
@@ -448,7 +446,6 @@ template <typename T, int N> struct FastSolver {
                     *dst = (row & 1) ? *dst + v : v;  // odd rows already hold the second-order rows (condense)
                 }
             }
-        (void)ee; (void)q;
         WSYNC();
         if (lane < n) {
             const int j = lane, jj = j & 1, k = j >> 1;
