@@ -6,17 +6,22 @@
 //   * INSTRUCTION FOOTPRINT.  A fully unrolled version of this kernel (109 KB of code) ran at
 //     ~1 byte of instructions per cycle per wave with no benefit from 4 waves per SIMD: it was
 //     instruction-fetch bound (the I-cache is 64 KB per CU pair).  So every loop over stages /
-//     columns is ROLLED, register arrays are indexed statically by shifting them one slot per
-//     step, and the roll-out, the linearisation and the factorisation each have ONE call site
-//     (the iteration is a small state machine: a line-search trial and the next iterate's
-//     evaluation are the same code).
+//     columns is ROLLED and the roll-out, the linearisation and the factorisation each have ONE
+//     call site (the iteration is a small state machine: a line-search trial and the next
+//     iterate's evaluation are the same code).
+//   * INSTRUCTION COUNT.  With the chip full the kernel is VALU-issue-bound (SQ counters in
+//     profiles/): ~8 k instructions per iteration at 4 issue cycles each.
 //   * no ds_bpermute / LDS round trips for scans and reductions: DPP row_shr / row_shl / row_bcast;
-//   * the condensed Hessian stays in the MFMA accumulators until it is written once, with the
-//     barrier terms, into a packed column-major LDS image (n(n+3)/2 words, 6.9 KB at N = 20);
-//     the stage second-derivative rows are rank-1 MFMAs into the same accumulators;
-//   * Cholesky keeps the active part of row i in the registers of lane i (N entries), in three
-//     rolled phases: columns 0..N-1, Schur update of the trailing block, columns N..2N-1.  The
-//     right-hand side rides along as row n, so the forward substitution is free.
+//   * condensing: the sensitivity recursion runs once per column (lane j = column j), its MFMA
+//     fragments are staged through a small LDS buffer, v_mfma_f64_16x16x4_f64 accumulates lower
+//     16x16 tiles; the tiles are written once, with the barrier terms, into a packed column-major
+//     LDS image (n(n+3)/2 words, 6.9 KB at N = 20, rhs as row n);
+//   * Cholesky: 4-column panels on the matrix cores (the 4x4 diagonal block redundantly in every
+//     lane, panel rows in MFMA fragment layout, one MFMA per trailing tile); what is stored is the
+//     block-LDL^T form L~ = L D^-1, so the substitutions are n/4 dependent block steps and the
+//     rhs row comes out solved through L~ and D;
+//   * wave-uniform scalars that are read once or twice per iteration, the best iterate, the
+//     gradient and the corrector terms live in LDS, not in VGPRs (2 waves per SIMD = 256 VGPRs).
 #include "kmpc_common.h"
 
 #define WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \

@@ -12,9 +12,13 @@
 //                   (c) condense: stream the 4 x 2k sensitivity block G_k through the stages
 //                       and accumulate H += G_k^T P_k G_k on the matrix cores
 //                       (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, K = nx = 4);
-//                   (d) KKT matrix K = sc*H + A^T Sigma A staged in LDS, in-wave Cholesky,
-//                       two triangular solves;
-//                   (e) fraction-to-the-boundary + Armijo back-tracking on the barrier function.
+//                   (d) KKT matrix K = sc*H + A^T Sigma A staged in LDS, blocked Cholesky on the
+//                       matrix cores (left-looking by 16-column tile column), triangular solves;
+//                   (e) Mehrotra predictor-corrector, fraction-to-the-boundary + Armijo
+//                       back-tracking on the barrier function.
+// This is the generic kernel: any horizon N <= 56 at run time, matrices in LDS; it also carries the
+// Frenet-frame model (MODEL = 1) as a second dynamics functor.  Horizons with a compile-time kernel
+// (kmpc_fast.hip) run there instead.
 //
 // Layouts
 //   n-vector  (length n = 2N, element j = 2k + {0: acc_k, 1: d_f_k}):  lane j%64, slot j/64
