@@ -34,7 +34,9 @@ for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     out["dispatches_averaged"] = r[1]
     out["scratch_bytes_per_lane"] = r[2]
     out["lds_bytes_per_wave"] = r[3]
-out["hbm_bytes_per_dispatch"] = 1024.0 * (out["FETCH_SIZE_KB_per_dispatch"] + out["WRITE_SIZE_KB_per_dispatch"])
+# FETCH_SIZE reports half of the bytes read on gfx950 (calibrated on 8 B and 24 B per lane reads: tools/calib/run.sh); WRITE_SIZE is exact
+out["hbm_bytes_per_dispatch_uncorrected"] = 1024.0 * (out["FETCH_SIZE_KB_per_dispatch"] + out["WRITE_SIZE_KB_per_dispatch"])
+out["hbm_bytes_per_dispatch"] = 1024.0 * (2 * out["FETCH_SIZE_KB_per_dispatch"] + out["WRITE_SIZE_KB_per_dispatch"])
 if note:
     out["build"] = note
 pj = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
