@@ -175,6 +175,9 @@ static KP make_kp(const kmpc_handle *h, int B, int warm, int hessian_override)
     memcpy(P.C, h->cost, sizeof P.C);
     P.tol = c.tol; P.mu_init = c.mu_init; P.relax = c.bound_relax; P.warm_push = c.warm_push; P.warm_mu = c.warm_mu;
     P.gap_tol = c.dtype == KMPC_F32 ? 1e-4 : 1e-7;
+    for (int i = 0; i < 8; ++i) P.C2[i] = 2.0 * P.C[i];
+    P.dt2 = P.dt * P.dt; P.dt_over_Lb = P.dt / P.L_b;
+    P.tol_x100 = 100.0 * P.tol; P.tol_x1000 = 1e3 * P.tol; P.tol_d100 = P.tol * 1e-2; P.tol_d10 = P.tol / 10.0;
     return P;
 }
 

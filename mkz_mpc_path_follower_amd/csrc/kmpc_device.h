@@ -10,6 +10,10 @@ struct KP {
     double steer_max, steer_dmax, a_max, a_dmax, v_min, v_max;
     double C[8];  // update_cost order: C_x, C_y, C_psi, C_v, C_dacc, C_ddf, C_acc, C_df
     double tol, mu_init, relax, warm_push, warm_mu, gap_tol;
+    // derived wave-uniform constants, computed once on the host: there is no scalar fp64 ALU, so a product like 2*C_x or 100*tol
+    // evaluated in the kernel occupies a VGPR pair for the whole solve once it is hoisted out of the loop (measured: ~30 spilled VGPRs)
+    double C2[8];  // 2 * C[i]
+    double dt2, dt_over_Lb, tol_x100, tol_x1000, tol_d100, tol_d10;
 };
 
 // device buffers of one batch (T = double / float)

@@ -112,6 +112,7 @@ template <typename T, int N> struct FastSolver {
     T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *gb, *cub, *clb, *sinvb;
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
     T dt, dtc, Lb, rr_, Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
+    T Cx2, Cy2, Cp2, Cv2, Cda2, Cdd2, Ca2, Cd2, dt2, dtL;  // 2*C_i, dt^2, dt/L_b from the host (KP: no scalar fp64 ALU on the device)
 
     DEV FastSolver(const KP &p, unsigned char *smem) : P(p), lane(threadIdx.x)
     {
@@ -130,6 +131,9 @@ template <typename T, int N> struct FastSolver {
         dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
         Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
         Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
+        Cx2 = (T)p.C2[0]; Cy2 = (T)p.C2[1]; Cp2 = (T)p.C2[2]; Cv2 = (T)p.C2[3];
+        Cda2 = (T)p.C2[4]; Cdd2 = (T)p.C2[5]; Ca2 = (T)p.C2[6]; Cd2 = (T)p.C2[7];
+        dt2 = (T)p.dt2; dtL = (T)p.dt_over_Lb;
     }
 
     DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)
@@ -228,15 +232,15 @@ template <typename T, int N> struct FastSolver {
         } else if (row == col + 2 && col >= 2 && col < R) {
             g = -wb[n + col];
         }
-        if (!((row | col) & 1)) g += dt * dt * cb[row >> 1];
+        if (!((row | col) & 1)) g += dt2 * cb[row >> 1];
         return g;
     }
     DEV T input_hess(int row, int col) const
     {
         const int jj = row & 1, k = row >> 1;
-        const T Cu = jj ? Cd : Ca, Cdl = jj ? Cdd : Cda;
-        if (row == col) return (T)2 * Cu + (T)2 * Cdl * (T)((k > 0) + (k < N - 1));
-        if (row == col + 2) return -(T)2 * Cdl;
+        const T Cu2 = jj ? Cd2 : Ca2, Cdl2 = jj ? Cdd2 : Cda2;
+        if (row == col) return Cu2 + Cdl2 * (T)((k > 0) + (k < N - 1));
+        if (row == col + 2) return -Cdl2;
         return (T)0;
     }
 
@@ -263,7 +267,7 @@ template <typename T, int N> struct FastSolver {
         S.b2 = rr_ * ((T)1 - rr_ * rr_) * ((T)2 * sd * cd) / (Dn * Dn);
         const T wp = st ? v * S.sinb : (T)0;
         const T ip = dpp_scan_prefix<SROWS>(wp);
-        const T psi = psi0 + (dt / Lb) * (ip - wp);
+        const T psi = psi0 + dtL * (ip - wp);
         T sp, cp;
         sincos_mid(psi, &sp, &cp);
         S.c = cp * S.cosb - sp * S.sinb;
@@ -289,11 +293,11 @@ template <typename T, int N> struct FastSolver {
     {
         const int k = lane;
         const bool st = k < N;
-        const T lx = (T)2 * Cx * S.ex, ly = (T)2 * Cy * S.ey, lp = (T)2 * Cp * S.ep, lv = (T)2 * Cv * S.ev;
+        const T lx = Cx2 * S.ex, ly = Cy2 * S.ey, lp = Cp2 * S.ep, lv = Cv2 * S.ev;
         const T px = dpp_scan_suffix<SROWS>(lx, lane), py = dpp_scan_suffix<SROWS>(ly, lane);
         const T px1 = dpp_mov0<0x130, 0xf>(px), py1 = dpp_mov0<0x130, 0xf>(py);  // wave_shl:1 -> value of lane+1
         const T A02 = st ? -dt * S.v * S.s : (T)0, A12 = st ? dt * S.v * S.c : (T)0;
-        const T A03 = st ? dt * S.c : (T)0, A13 = st ? dt * S.s : (T)0, A23 = st ? dt / Lb * S.sinb : (T)0;
+        const T A03 = st ? dt * S.c : (T)0, A13 = st ? dt * S.s : (T)0, A23 = st ? dtL * S.sinb : (T)0;
         const T tp = lp + (st ? A02 * px1 + A12 * py1 : (T)0);
         const T pp = dpp_scan_suffix<SROWS>(tp, lane);
         const T pp1 = dpp_mov0<0x130, 0xf>(pp);
@@ -304,9 +308,9 @@ template <typename T, int N> struct FastSolver {
         const T Bdp = st ? dt * S.v / Lb * S.cosb * S.b1 : (T)0;
         const T aprev = dpp_mov0<0x138, 0xf>(S.a), dprev = dpp_mov0<0x138, 0xf>(S.d);  // wave_shr:1 -> lane-1
         const T anext = dpp_mov0<0x130, 0xf>(S.a), dnext = dpp_mov0<0x130, 0xf>(S.d);
-        T ga = dt * pv1 + (T)2 * Ca * S.a, gd = Bdx * px1 + Bdy * py1 + Bdp * pp1 + (T)2 * Cd * S.d;
-        if (k >= 1) { ga += (T)2 * Cda * (S.a - aprev); gd += (T)2 * Cdd * (S.d - dprev); }
-        if (k < N - 1) { ga -= (T)2 * Cda * (anext - S.a); gd -= (T)2 * Cdd * (dnext - S.d); }
+        T ga = dt * pv1 + Ca2 * S.a, gd = Bdx * px1 + Bdy * py1 + Bdp * pp1 + Cd2 * S.d;
+        if (k >= 1) { ga += Cda2 * (S.a - aprev); gd += Cdd2 * (S.d - dprev); }
+        if (k < N - 1) { ga -= Cda2 * (anext - S.a); gd -= Cdd2 * (dnext - S.d); }
         if (st) { xb[2 * k] = ga; xb[2 * k + 1] = gd; }
         T mpp = 0, mpv = 0, mpd = 0, mvd = 0, mdd = 0;
         if (exact && st) {
@@ -314,7 +318,7 @@ template <typename T, int N> struct FastSolver {
             mpp = px1 * (-dt * v * c) + py1 * (-dt * v * s);
             mpv = px1 * (-dt * s) + py1 * (dt * c);
             mpd = px1 * (-dt * v * c * b1) + py1 * (-dt * v * s * b1);
-            mvd = px1 * (-dt * s * b1) + py1 * (dt * c * b1) + pp1 * (dt / Lb * S.cosb * b1);
+            mvd = px1 * (-dt * s * b1) + py1 * (dt * c * b1) + pp1 * (dtL * S.cosb * b1);
             mdd = px1 * (-dt * v * (c * b1 * b1 + s * b2)) + py1 * (dt * v * (-s * b1 * b1 + c * b2)) +
                   pp1 * (dt * v / Lb * (-S.sinb * b1 * b1 + S.cosb * b2));
         }
@@ -384,12 +388,12 @@ template <typename T, int N> struct FastSolver {
             S.gp = fma(ind, S.cur.bp, S.gp);
             S.gv += isnew ? gvnew : (T)0;
             // weights of state s+1: 2Q_{s+1} + M_{s+1}^{psi,v}
-            const T Cv1 = s + 1 <= N - 1 ? (T)2 * Cv : (T)0;
+            const T Cv1 = s + 1 <= N - 1 ? Cv2 : (T)0;
             // component-major staging: opb[comp][col]
             opb[0 * 64 + lane] = S.gx; opb[1 * 64 + lane] = S.gy; opb[2 * 64 + lane] = S.gp; opb[3 * 64 + lane] = S.gv;
-            opb[4 * 64 + lane] = (T)2 * Cx * S.gx;
-            opb[5 * 64 + lane] = (T)2 * Cy * S.gy;
-            opb[6 * 64 + lane] = ((T)2 * Cp + nxt.mpp) * S.gp + nxt.mpv * S.gv;
+            opb[4 * 64 + lane] = Cx2 * S.gx;
+            opb[5 * 64 + lane] = Cy2 * S.gy;
+            opb[6 * 64 + lane] = (Cp2 + nxt.mpp) * S.gp + nxt.mpv * S.gv;
             opb[7 * 64 + lane] = Cv1 * S.gv + nxt.mpv * S.gp;
             WFENCE();
             // the record fetched at the top of this trip is long complete: take its (free) wait HERE, before the fragment reads are
@@ -434,7 +438,6 @@ template <typename T, int N> struct FastSolver {
     DEV void build_K(const acc_t (&acc)[NTT], T sc, T reg, T rhs)
     {
         const int c = lane & 15;
-        const T dt2 = dt * dt;
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -454,8 +457,8 @@ template <typename T, int N> struct FastSolver {
         WSYNC();
         if (lane < n) {
             const int j = lane, jj = j & 1, k = j >> 1;
-            const T Cu = jj ? Cd : Ca, Cdl = jj ? Cdd : Cda;
-            T dg = wb[j] + sc * ((T)2 * Cu + (T)2 * Cdl * (T)((k > 0) + (k < N - 1))) + reg;
+            const T Cu2 = jj ? Cd2 : Ca2, Cdl2 = jj ? Cdd2 : Cda2;
+            T dg = wb[j] + sc * (Cu2 + Cdl2 * (T)((k > 0) + (k < N - 1))) + reg;
             if (j < 2) dg += wb[n + j];
             if (j >= 4) dg += wb[n + j - 2];
             const bool rate = j >= 2 && j < R;
@@ -463,7 +466,7 @@ template <typename T, int N> struct FastSolver {
             dg += wr;
             T *pd = Lc + offc_rt(j);
             pd[j] += dg;
-            if (j + 2 < n) pd[j + 2] += -wr - sc * (T)2 * Cdl;
+            if (j + 2 < n) pd[j + 2] += -wr - sc * Cdl2;
             pd[n] = rhs;
         }
         WSYNC();
@@ -787,7 +790,7 @@ template <typename T, int N> struct FastSolver {
                     // safeguard: the corrected direction is tried at the full step only; redo the step without the corrector term
                     if (corr_active) { mode = RESTEP; Ut = U; continue; }
                     if (++ls >= P.max_ls) {
-                        status = cs[C_ERR] <= (T)100 * tol ? 0 : 3; mode = FINAL; Ut = U; continue;  // acceptable level
+                        status = cs[C_ERR] <= (T)P.tol_x100 ? 0 : 3; mode = FINAL; Ut = U; continue;  // acceptable level
                     }
                     alpha *= (T)0.5;
                     Ut = U + alpha * du;
@@ -798,7 +801,7 @@ template <typename T, int N> struct FastSolver {
                 {
                     const T stepn = dpp_max(fabs(alpha * du)), umax = fmax((T)1, dpp_max(fabs(U)));
                     n_tiny = stepn <= (T)10 * Real<T>::eps() * umax ? n_tiny + 1 : 0;
-                    if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= (T)1e3 * tol ? 0 : 3; tiny_stop = true; mode = FINAL; continue; }
+                    if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= (T)P.tol_x1000 ? 0 : 3; tiny_stop = true; mode = FINAL; continue; }
                 }
                 // accepted: dual step from the pre-step slacks, then the slacks advance with the step
                 const T ad = cs[C_AD];
@@ -867,9 +870,9 @@ template <typename T, int N> struct FastSolver {
                 if (err0 <= tol) {
                     if (gap / sc <= gap_lim || n_polish >= 1) done = true; else ++n_polish;
                 } else if (n_polish > 0 && ++n_polish > 1) done = true;
-                n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
+                n_accept = err0 <= (T)P.tol_x100 ? n_accept + 1 : 0;
                 if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
-                const T mu_min = fmax(tol * (T)1e-2, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
+                const T mu_min = fmax((T)P.tol_d100, fmin((T)P.tol_d10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
                 cs[C_MUF] = mu_min;
 #pragma nounroll
                 for (; !pc;) {  // monotone barrier update (mu_strategy 0)
@@ -1025,14 +1028,6 @@ template <typename T, int N> struct FastSolver {
         }
         STAMP(11);
         STAMP_OUT(io.stamps, b);
-#ifdef KMPC_STAMPS
-        // diagnostic build only: final optimality error, barrier parameter and last step length in the stamp slots 13..15
-        if (io.stamps && lane == 0) {
-            io.stamps[(size_t)b * 16 + 13] = (unsigned long long)__double_as_longlong((double)cs[C_ERR]);
-            io.stamps[(size_t)b * 16 + 14] = (unsigned long long)__double_as_longlong((double)mu);
-            io.stamps[(size_t)b * 16 + 15] = (unsigned long long)__double_as_longlong((double)alpha);
-        }
-#endif
         if (lane == 0) {
             io.status[b] = status;
             if (io.cost) io.cost[b] = Jt;
