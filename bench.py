@@ -147,8 +147,8 @@ def cpu_baseline(N, d, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
