@@ -111,7 +111,7 @@ template <typename T, int N> struct FastSolver {
                // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
     T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *gb, *cub, *clb, *sinvb;
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
-    T dt, dtc, Lb, rr_, Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
+    T dt, dtc, rr_;
     T Cx2, Cy2, Cp2, Cv2, Cda2, Cdd2, Ca2, Cd2, dt2, dtL;  // 2*C_i, dt^2, dt/L_b from the host (KP: no scalar fp64 ALU on the device)
 
     DEV FastSolver(const KP &p, unsigned char *smem) : P(p), lane(threadIdx.x)
@@ -128,9 +128,7 @@ template <typename T, int N> struct FastSolver {
         cub = gb + 64; clb = cub + 64 * NF;  // corrector terms
         sinvb = clb + 64 * NF;  // D_j^-1 of the factor's 4x4 diagonal blocks (row-major, 16 per 4-column panel)
         for (int e = lane; e < 16 * (n / 4); e += 64) sinvb[e] = (T)0;
-        dt = (T)p.dt; dtc = (T)p.dtc; Lb = (T)p.L_b; rr_ = (T)p.r;
-        Cx = (T)p.C[0]; Cy = (T)p.C[1]; Cp = (T)p.C[2]; Cv = (T)p.C[3];
-        Cda = (T)p.C[4]; Cdd = (T)p.C[5]; Ca = (T)p.C[6]; Cd = (T)p.C[7];
+        dt = (T)p.dt; dtc = (T)p.dtc; rr_ = (T)p.r;
         Cx2 = (T)p.C2[0]; Cy2 = (T)p.C2[1]; Cp2 = (T)p.C2[2]; Cv2 = (T)p.C2[3];
         Cda2 = (T)p.C2[4]; Cdd2 = (T)p.C2[5]; Ca2 = (T)p.C2[6]; Cd2 = (T)p.C2[7];
         dt2 = (T)p.dt2; dtL = (T)p.dt_over_Lb;
@@ -282,9 +280,11 @@ template <typename T, int N> struct FastSolver {
         S.ey = cs ? S.y - ry : (T)0;
         S.ep = cs ? psi - rp : (T)0;
         S.ev = (k >= 1 && k <= N - 1) ? v - vt : (T)0;
-        T Jl = Cx * S.ex * S.ex + Cy * S.ey * S.ey + Cp * S.ep * S.ep + Cv * S.ev * S.ev;
-        if (st) Jl += Ca * a * a + Cd * d * d;
-        if (k < N - 1) Jl += Cda * (an - a) * (an - a) + Cdd * (dn - d) * (dn - d);
+        // (the weights are held doubled -- the form every derivative needs; halving the sum is exact)
+        T Jl = Cx2 * S.ex * S.ex + Cy2 * S.ey * S.ey + Cp2 * S.ep * S.ep + Cv2 * S.ev * S.ev;
+        if (st) Jl += Ca2 * a * a + Cd2 * d * d;
+        if (k < N - 1) Jl += Cda2 * (an - a) * (an - a) + Cdd2 * (dn - d) * (dn - d);
+        Jl *= (T)0.5;
         return dpp_sum(Jl);
     }
 
@@ -305,7 +305,7 @@ template <typename T, int N> struct FastSolver {
         const T pv = dpp_scan_suffix<SROWS>(tv, lane);
         const T pv1 = dpp_mov0<0x130, 0xf>(pv);
         const T Bdx = st ? -dt * S.v * S.s * S.b1 : (T)0, Bdy = st ? dt * S.v * S.c * S.b1 : (T)0;
-        const T Bdp = st ? dt * S.v / Lb * S.cosb * S.b1 : (T)0;
+        const T Bdp = st ? dtL * S.v * S.cosb * S.b1 : (T)0;
         const T aprev = dpp_mov0<0x138, 0xf>(S.a), dprev = dpp_mov0<0x138, 0xf>(S.d);  // wave_shr:1 -> lane-1
         const T anext = dpp_mov0<0x130, 0xf>(S.a), dnext = dpp_mov0<0x130, 0xf>(S.d);
         T ga = dt * pv1 + Ca2 * S.a, gd = Bdx * px1 + Bdy * py1 + Bdp * pp1 + Cd2 * S.d;
@@ -320,7 +320,7 @@ template <typename T, int N> struct FastSolver {
             mpd = px1 * (-dt * v * c * b1) + py1 * (-dt * v * s * b1);
             mvd = px1 * (-dt * s * b1) + py1 * (dt * c * b1) + pp1 * (dtL * S.cosb * b1);
             mdd = px1 * (-dt * v * (c * b1 * b1 + s * b2)) + py1 * (dt * v * (-s * b1 * b1 + c * b2)) +
-                  pp1 * (dt * v / Lb * (-S.sinb * b1 * b1 + S.cosb * b2));
+                  pp1 * (dtL * v * (-S.sinb * b1 * b1 + S.cosb * b2));
         }
         {
             T *q = lin + LIN_STRIDE * (k <= N ? k : N);
