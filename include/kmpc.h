@@ -52,7 +52,7 @@ enum {
 
 /* Replaces the module-level constants of MKZMPCPathFollower.jl:28-48 and the Ipopt options of :29. */
 typedef struct kmpc_config {
-    int32_t N;          /* horizon (:34, default 8); supported 2..56 */
+    int32_t N;          /* horizon (:34, default 8); supported 2..56 (compile-time-horizon kernels for 8, 12, 16, 20, 24, 28) */
     int32_t dtype;      /* KMPC_F64 / KMPC_F32: arithmetic AND device-buffer element type */
     double dt;          /* :33  0.20 */
     double dt_control;  /* :28  0.10 */
@@ -81,7 +81,7 @@ typedef struct kmpc_config {
                                Calls on one handle must be stream-ordered (the permutation workspace belongs to the handle). */
     int32_t model;          /* 0 (default) = MKZMPCPathFollower.jl, Cartesian states (x, y, psi, v); 1 = MKZMPCPathFollowerFrenet.jl,
                                Frenet-frame states (s, e_y, e_psi, v) with a cubic curvature polynomial (kmpc_solve_batch_frenet;
-                               Gauss-Newton Hessian, horizons N <= 24).  kmpc_create picks the cost defaults of the chosen module. */
+                               horizons N <= 24).  kmpc_create picks the cost defaults of the chosen module. */
 } kmpc_config;
 
 typedef struct kmpc_handle kmpc_handle;
