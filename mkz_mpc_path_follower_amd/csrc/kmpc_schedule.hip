@@ -5,10 +5,12 @@
 // problem) + (that problem's solve time).  Workgroups are dispatched in index order, so starting the problems that
 // are expected to run longest FIRST takes the first term to zero (LPT list scheduling).  The predictor is two terms
 // of the inputs that a least-squares fit on the iteration counts of synthetic batches singled out:
-//     key = |v0 - v_ref| + 1.33 * sum_k |psi_ref[k+1] - psi_ref[k]|,   v_ref = mean reference spacing / dt
-// (speed mismatch against the reference sampling -- the cause of long active-constraint phases -- and how much the
-// reference turns).  With this key the simulated makespan of the BASELINE configs[1] batch reaches its lower bound
-// (the slowest problem) instead of 1.4x above it.  Results do not depend on the order.
+//     key = |v0 - v_ref| + 0.3 * sum_k |psi_ref[k+1] - psi_ref[k]|,   v_ref = mean reference spacing / dt
+// (speed mismatch against the reference sampling -- the cause of long active-constraint phases and, when the car is
+// too fast for its reference, of the non-convex "swerve to lose distance" optima that take 20+ iterations -- and, as
+// a tie-breaker, how much the reference turns).  Mean launch time of 4096 problems over 8 synthetic batches, index
+// order -> this key: see DESIGN.md section 2; a turn weight of 1.33 (an earlier fit) is 0-11 % slower at N = 12..28.
+// Results do not depend on the order.
 //
 // Implementation: a 256-bucket counting sort on the quantised key in two small kernels -- keys + histogram ranks
 // (atomics), then prefix + scatter -- into a permutation the solve kernels index through (KIO::perm).
@@ -29,8 +31,8 @@ __global__ __launch_bounds__(256) void kmpc_sched_keys(int B, int N, double dt, 
         turn += fabs(pn - ps);
         x = xn; y = yn; ps = pn;
     }
-    const double key = fabs((double)z0[4 * (size_t)i + 3] - (double)len / (N * dt)) + 1.33 * (double)turn;
-    int q = (int)(key * 24.0);                 // keys live in [0, ~10]
+    const double key = fabs((double)z0[4 * (size_t)i + 3] - (double)len / (N * dt)) + 0.3 * (double)turn;
+    int q = (int)(key * 48.0);                 // 1/48 m/s resolution; everything above 5.3 shares the first bucket
     q = q < 0 || !(key == key) ? 0 : (q > 255 ? 255 : q);
     const uint32_t bucket = 255u - (uint32_t)q;  // bucket 0 = longest
     const uint32_t pos = atomicAdd(&hist[bucket], 1u);
