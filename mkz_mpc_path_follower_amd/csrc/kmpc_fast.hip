@@ -34,8 +34,19 @@ DEV double rsqrt_(double d) {
     double y = __builtin_amdgcn_rsq(d);          // ~2^-26 relative
     double e = fma(-d * y, y, 1.0);
     y = fma(y * e, fma(e, 0.375, 0.5), y);      // cubic step: ~2^-78
-    e = fma(-d * y, y, 1.0);
-    return fma(y * e, 0.5, y);                  // polish (guards the approximation's worst case)
+    return y;
+}
+// reciprocal without the IEEE division's scaling / fix-up sequence (operands here are well inside the normal range): ~1 ulp
+DEV double rcp_(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    return fma(y, e, y);
+}
+DEV float rcp_(float d) {
+    const float y = __builtin_amdgcn_rcpf(d);
+    return fmaf(y, fmaf(-d, y, 1.0f), y);
 }
 DEV float rsqrt_(float d) {
     float y = __builtin_amdgcn_rsqf(d);
@@ -261,8 +272,9 @@ template <typename T, int N> struct FastSolver {
         const T rs = rsqrt_(Dn);
         S.sinb = rr_ * sd * rs;
         S.cosb = cd * rs;
-        S.b1 = rr_ / Dn;
-        S.b2 = rr_ * ((T)1 - rr_ * rr_) * ((T)2 * sd * cd) / (Dn * Dn);
+        const T iD = rs * rs;  // 1 / Dn
+        S.b1 = rr_ * iD;
+        S.b2 = rr_ * ((T)1 - rr_ * rr_) * ((T)2 * sd * cd) * (iD * iD);
         const T wp = st ? v * S.sinb : (T)0;
         const T ip = dpp_scan_prefix<SROWS>(wp);
         const T psi = psi0 + dtL * (ip - wp);
@@ -721,7 +733,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; lu[i] = ll[i] = sup[i] = slo[i] = isu[i] = isl[i] = aut[i] = (T)0; }
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
-        enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J };
+        enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J, C_LGS };
         cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_AD] = 0; cs[C_J] = 0;
         int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
         bool have_best = false;
@@ -775,16 +787,21 @@ template <typename T, int N> struct FastSolver {
             STAMP(9);
             if (mode == FINAL) break;
             if (mode == TRIAL) {
-                T lgt = 0;
+                // sum of log(slack) over the forms of this lane: one log of the product (fp64 range is ample; fp32 takes one per register)
+                T lgt = 0, lpr = 1;
                 bool okp = true;
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
                         const T a_ = sup[i] - alpha * aut[i], b_ = slo[i] + alpha * aut[i];
-                        if (!(a_ > 0) || !(b_ > 0)) okp = false; else lgt += log(a_ * b_);
+                        if (!(a_ > 0) || !(b_ > 0)) okp = false;
+                        else if (sizeof(T) == 8) lpr *= a_ * b_;
+                        else lgt += log(a_ * b_);
                     }
+                if (sizeof(T) == 8) lgt = log(lpr);
                 okp = __all(okp);
-                const T phi = sc * Jt - mu * dpp_sum(lgt);
+                const T slg = dpp_sum(lgt);
+                const T phi = sc * Jt - mu * slg;
                 const T phi0 = cs[C_PHI0];
                 if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * cs[C_DPHI])) {
                     // safeguard: the corrected direction is tried at the full step only; redo the step without the corrector term
@@ -804,6 +821,7 @@ template <typename T, int N> struct FastSolver {
                     if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= (T)P.tol_x1000 ? 0 : 3; tiny_stop = true; mode = FINAL; continue; }
                 }
                 // accepted: dual step from the pre-step slacks, then the slacks advance with the step
+                cs[C_LGS] = slg;  // = sum log(slack) of the new iterate: the next barrier value re-uses it
                 const T ad = cs[C_AD];
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
@@ -813,7 +831,7 @@ template <typename T, int N> struct FastSolver {
                         ll[i] += ad * ((mu - clb[lane + 64 * i] - ll[i] * sl) * isl[i] - ll[i] * isl[i] * aut[i]);
                         sup[i] = su - alpha * aut[i];
                         slo[i] = sl + alpha * aut[i];
-                        isu[i] = (T)1 / sup[i]; isl[i] = (T)1 / slo[i];
+                        isu[i] = rcp_(sup[i]); isl[i] = rcp_(slo[i]);
                     }
             }
             const bool restep = mode == RESTEP;
@@ -832,6 +850,12 @@ template <typename T, int N> struct FastSolver {
                         sup[i] = bu_ - w[i]; slo[i] = bl_ + w[i];
                         isu[i] = fv[i] ? (T)1 / sup[i] : (T)0; isl[i] = fv[i] ? (T)1 / slo[i] : (T)0;
                     }
+                    {
+                        T lg0 = 0;
+#pragma unroll
+                        for (int i = 0; i < NF; ++i) if (fv[i]) lg0 += log(sup[i] * slo[i]);
+                        cs[C_LGS] = dpp_sum(lg0);
+                    }
                     const T gm = dpp_max(fabs(g));
                     sc = gm > (T)100 ? (T)100 / gm : (T)1;  // Ipopt nlp_scaling_max_gradient
 #pragma unroll
@@ -840,8 +864,8 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
                         if (fv[i]) {
-                            lu[i] = fmax(fmin(lu[i], kappa_sigma * mu * isu[i]), mu * isu[i] / kappa_sigma);
-                            ll[i] = fmax(fmin(ll[i], kappa_sigma * mu * isl[i]), mu * isl[i] / kappa_sigma);
+                            lu[i] = fmax(fmin(lu[i], kappa_sigma * mu * isu[i]), mu * isu[i] * ((T)1 / kappa_sigma));
+                            ll[i] = fmax(fmin(ll[i], kappa_sigma * mu * isl[i]), mu * isl[i] * ((T)1 / kappa_sigma));
                         }
                 }
                 if (iters >= P.max_iter) { mode = FINAL; Ut = U; continue; }  // status stays ITERATION_LIMIT
@@ -859,20 +883,21 @@ template <typename T, int N> struct FastSolver {
                     }
                 const T rdm = dpp_max(fabs(rd));
                 lsum = dpp_sum(lsum); cm0 = dpp_max(cm0); gap = dpp_sum(gap);
-                const T s_d = fmax(s_max, lsum / (T)(2 * nf)) / s_max;
-                const T err0 = fmax(rdm, cm0) / s_d;
+                constexpr T inv2nf = (T)1 / (T)(2 * nf);
+                const T isd = s_max * rcp_(fmax(s_max, lsum * inv2nf));  // 1 / s_d
+                const T err0 = fmax(rdm, cm0) * isd;
                 const T gap_lim = gap_tol * fmax((T)1, fabs(Jt));
-                cs[C_ERR] = err0; cs[C_RDS] = rdm / s_d;
+                cs[C_ERR] = err0; cs[C_RDS] = rdm * isd;
                 // Ipopt's test (+ gap bound, pursued for at most 1 more iteration once Ipopt's test is met), or
                 // Ipopt's "acceptable level" (error <= 100*tol for 15 iterations in a row)
                 bool done = false;
                 if (err0 <= tol) { ubest[lane] = U; have_best = true; }  // last iterate passing Ipopt's test
                 if (err0 <= tol) {
-                    if (gap / sc <= gap_lim || n_polish >= 1) done = true; else ++n_polish;
+                    if (gap <= gap_lim * sc || n_polish >= 1) done = true; else ++n_polish;
                 } else if (n_polish > 0 && ++n_polish > 1) done = true;
                 n_accept = err0 <= (T)P.tol_x100 ? n_accept + 1 : 0;
                 if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
-                const T mu_min = fmax((T)P.tol_d100, fmin((T)P.tol_d10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
+                const T mu_min = fmax((T)P.tol_d100, fmin((T)P.tol_d10, (T)0.1 * gap_lim * sc * inv2nf));
                 cs[C_MUF] = mu_min;
 #pragma nounroll
                 for (; !pc;) {  // monotone barrier update (mu_strategy 0)
@@ -881,7 +906,7 @@ template <typename T, int N> struct FastSolver {
                     for (int i = 0; i < NF; ++i)
                         if (fv[i]) cmu = fmax(cmu, fmax(fabs(sup[i] * lu[i] - mu), fabs(slo[i] * ll[i] - mu)));
                     cmu = dpp_max(cmu);
-                    if (fmax(rdm, cmu) / s_d <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, mu * sqrt(mu)));
+                    if (fmax(rdm, cmu) * isd <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, mu * sqrt(mu)));
                     else break;
                 }
                 use_exact = exact && gn_hold == 0; reg = 0; attempt = 0;  // GN is held for 2 iterations after an indefinite exact Hessian
@@ -954,7 +979,7 @@ template <typename T, int N> struct FastSolver {
                         rda = fmax(rda, fmax((T)1 - qu, (T)1 + ql));
                         mucur += sup[i] * lu[i] + slo[i] * ll[i];
                     }
-                const T apa = (T)1 / dpp_max(rpa), ada = (T)1 / dpp_max(rda);
+                const T apa = rcp_(dpp_max(rpa)), ada = rcp_(dpp_max(rda));
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
@@ -963,10 +988,10 @@ template <typename T, int N> struct FastSolver {
                         muaff += (su + apa * dsu) * (lu[i] + ada * dlu) + (sl + apa * dsl) * (ll[i] + ada * dll);
                         cub[lane + 64 * i] = dsu * dlu; clb[lane + 64 * i] = dsl * dll;
                     }
-                mucur = dpp_sum(mucur) / (T)(2 * nf); muaff = dpp_sum(muaff) / (T)(2 * nf);
-                const T r3 = muaff / mucur;
+                mucur = dpp_sum(mucur) * ((T)1 / (T)(2 * nf)); muaff = dpp_sum(muaff) * ((T)1 / (T)(2 * nf));
+                const T r3 = muaff * rcp_(mucur);
                 mu = fmax(cs[C_MUF], fmin((T)1, r3 * r3 * r3) * mucur);
-                mu = fmax(mu, fmin(mucur, cs[C_RDS] / (T)1e3));  // no barrier target far below the dual infeasibility
+                mu = fmax(mu, fmin(mucur, cs[C_RDS] * (T)1e-3));  // no barrier target far below the dual infeasibility
                 corr_active = true;
                 STAMP(7);
             }
@@ -982,7 +1007,7 @@ template <typename T, int N> struct FastSolver {
             STAMP(15);
             forms_apply(du, aut);
             const T tau = fmax(tau_min, (T)1 - mu);
-            T rp = 0, rq = 0, lg = 0, gw = 0;
+            T rp = 0, rq = 0, gw = 0;
 #pragma unroll
             for (int i = 0; i < NF; ++i)
                 if (fv[i]) {
@@ -991,13 +1016,12 @@ template <typename T, int N> struct FastSolver {
                     const T dll = (mu - clb[lane + 64 * i] - ll[i] * sl) * isl[i] - ll[i] * isl[i] * dsl;
                     gw += mu * (isu[i] - isl[i]) * aut[i];
                     rp = fmax(rp, fmax(-dsu * isu[i], -dsl * isl[i]));
-                    rq = fmax(rq, fmax(-dlu / lu[i], -dll / ll[i]));
-                    lg += log(su * sl);
+                    rq = fmax(rq, fmax(-dlu * rcp_(lu[i]), -dll * rcp_(ll[i])));
                 }
             // fraction to the boundary: alpha = min(1, tau * min(-s/ds)) = tau / max(tau, max(-ds/s))
-            const T ap = tau / fmax(tau, dpp_max(rp));
-            cs[C_AD] = tau / fmax(tau, dpp_max(rq));
-            cs[C_PHI0] = sc * cs[C_J] - mu * dpp_sum(lg);
+            const T ap = tau * rcp_(fmax(tau, dpp_max(rp)));
+            cs[C_AD] = tau * rcp_(fmax(tau, dpp_max(rq)));
+            cs[C_PHI0] = sc * cs[C_J] - mu * cs[C_LGS];
             cs[C_DPHI] = dpp_sum((lane < n ? sc * gb[lane] * du : (T)0) + gw);  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
             alpha = ap; ls = 0;
             Ut = U + alpha * du;
