@@ -39,7 +39,7 @@ struct kmpc_handle {
 
 static std::string g_create_err;
 static unsigned long long *g_stamps = nullptr;  // set by kmpc_debug_set_stamps in diagnostic builds
-#ifdef KMPC_STAMPS
+#if defined(KMPC_STAMPS) || defined(KMPC_TRACE)
 extern "C" int32_t kmpc_debug_set_stamps(void *p) { g_stamps = (unsigned long long *)p; return 0; }
 #endif
 

@@ -50,8 +50,16 @@ template <typename T> DEV T scan_suffix(T x, int lane) {  // inclusive, lane 63 
 }
 #define WSYNC() __syncthreads()
 
-// phase stamps: diagnostic builds only (-DKMPC_STAMPS); the shipped library has none
-#ifdef KMPC_STAMPS
+// phase stamps: diagnostic builds only (-DKMPC_STAMPS); the shipped library has none.  -DKMPC_TRACE (diagnostic too) turns the
+// stamp buffer into a per-iteration record of one problem: row `it` = 8 doubles (tools/trace_problem.py)
+#ifdef KMPC_TRACE
+#define STAMP_MEMBERS
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_OUT(ptr, b)
+#define TRACE8(ptr, it, a0, a1, a2, a3, a4, a5, a6, a7) do { if ((ptr) && threadIdx.x == 0 && (it) < 256) { double *q_ = (double *)(ptr) + 8 * (it); \
+    q_[0] = (double)(a0); q_[1] = (double)(a1); q_[2] = (double)(a2); q_[3] = (double)(a3); q_[4] = (double)(a4); q_[5] = (double)(a5); q_[6] = (double)(a6); q_[7] = (double)(a7); } } while (0)
+#elif defined(KMPC_STAMPS)
 #define STAMP_MEMBERS unsigned long long st_t0_, st_acc_[16];
 #define STAMP_DECL do { st_t0_ = __builtin_readcyclecounter(); for (int i_ = 0; i_ < 16; ++i_) st_acc_[i_] = 0; } while (0);
 #define STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc_[i] += t_ - st_t0_; st_t0_ = t_; } while (0)
@@ -61,6 +69,9 @@ template <typename T> DEV T scan_suffix(T x, int lane) {  // inclusive, lane 63 
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_OUT(ptr, b)
+#endif
+#ifndef TRACE8
+#define TRACE8(ptr, it, a0, a1, a2, a3, a4, a5, a6, a7)
 #endif
 
 

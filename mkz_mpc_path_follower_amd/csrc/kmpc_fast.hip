@@ -102,6 +102,9 @@ template <typename T> struct StageF {  // lane k: state k / input k at the evalu
 // A02 A03 A12 A13 A23 Bdx Bdy Bdp mpp mpv mpd mvd mdd 0
 constexpr int LIN_STRIDE = 16;
 
+#ifndef KMPC_IKRD
+#define KMPC_IKRD 1e-3
+#endif
 template <typename T, int N> struct FastSolver {
     static constexpr int n = 2 * N, R = 2 * (N - 1), nf = 5 * N - 2;
     static constexpr int NF = (nf + 63) / 64;
@@ -733,8 +736,8 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; lu[i] = ll[i] = sup[i] = slo[i] = isu[i] = isl[i] = aut[i] = (T)0; }
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
-        enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J, C_LGS };
-        cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_AD] = 0; cs[C_J] = 0;
+        enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J, C_LGS, C_JP };
+        cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_AD] = 0; cs[C_J] = 0; cs[C_JP] = (T)1e30;
         int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
         bool have_best = false;
         T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, Jt = 0, alpha = 0, reg = 0;
@@ -742,7 +745,7 @@ template <typename T, int N> struct FastSolver {
         enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3, RESTEP = 4 };
         const bool pc = P.mu_strategy == 1;
         bool corr_active = false, first_attempt = true, tiny_stop = false;
-        int n_tiny = 0;
+        int n_tiny = 0, n_flat = 0;
 #pragma unroll
         for (int i = 0; i < NF; ++i) cub[lane + 64 * i] = clb[lane + 64 * i] = (T)0;
         int mode = FIRST;
@@ -888,6 +891,7 @@ template <typename T, int N> struct FastSolver {
                 const T err0 = fmax(rdm, cm0) * isd;
                 const T gap_lim = gap_tol * fmax((T)1, fabs(Jt));
                 cs[C_ERR] = err0; cs[C_RDS] = rdm * isd;
+                TRACE8(io.stamps, iters, err0, rdm * isd, cm0 * isd, mu, Jt, alpha, ls, (use_exact ? 1 : 0) + 2 * indef + 4 * (int)corr_active + 8 * n_tiny);
                 // Ipopt's test (+ gap bound, pursued for at most 1 more iteration once Ipopt's test is met), or
                 // Ipopt's "acceptable level" (error <= 100*tol for 15 iterations in a row)
                 bool done = false;
@@ -896,6 +900,11 @@ template <typename T, int N> struct FastSolver {
                     if (gap <= gap_lim * sc || n_polish >= 1) done = true; else ++n_polish;
                 } else if (n_polish > 0 && ++n_polish > 1) done = true;
                 n_accept = err0 <= (T)P.tol_x100 ? n_accept + 1 : 0;
+                // rounding floor: the objective has not moved by more than 20 eps |J| for 12 iterations in a row -> the arithmetic cannot
+                // improve the iterate (fp32, large costs: the dual residual never settles below 100 tol); Optimal within 1e3 tol
+                n_flat = fabs(Jt - cs[C_JP]) <= (T)20 * Real<T>::eps() * fmax((T)1, fabs(Jt)) ? n_flat + 1 : 0;
+                cs[C_JP] = Jt;
+                if (n_flat >= 12 && err0 <= (T)P.tol_x1000) done = true;
                 if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
                 const T mu_min = fmax((T)P.tol_d100, fmin((T)P.tol_d10, (T)0.1 * gap_lim * sc * inv2nf));
                 cs[C_MUF] = mu_min;
@@ -991,7 +1000,7 @@ template <typename T, int N> struct FastSolver {
                 mucur = dpp_sum(mucur) * ((T)1 / (T)(2 * nf)); muaff = dpp_sum(muaff) * ((T)1 / (T)(2 * nf));
                 const T r3 = muaff * rcp_(mucur);
                 mu = fmax(cs[C_MUF], fmin((T)1, r3 * r3 * r3) * mucur);
-                mu = fmax(mu, fmin(mucur, cs[C_RDS] * (T)1e-3));  // no barrier target far below the dual infeasibility
+                mu = fmax(mu, fmin(mucur, cs[C_RDS] * (T)KMPC_IKRD));  // no barrier target far below the dual infeasibility
                 corr_active = true;
                 STAMP(7);
             }

@@ -848,7 +848,8 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         bool fv[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i], rlx[i]); }
-        int status = 1, iters = 0, n_polish = 0, n_accept = 0, gn_hold = 0, n_tiny = 0;
+        int status = 1, iters = 0, n_polish = 0, n_accept = 0, gn_hold = 0, n_tiny = 0, n_flat = 0;
+        T J_prev = (T)1e30;
         bool tiny_stop = false;
         T dw_last = 0, dw_spec = 0, hmax = 0;
         int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
@@ -945,6 +946,11 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                 } else if (n_polish > 0 && ++n_polish > 1) { status = 0; break; }
                 n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
                 if (n_accept >= 15) { status = 0; break; }
+                // rounding floor: the objective has not moved by more than 20 eps |J| for 12 iterations in a row -> the arithmetic cannot
+                // improve the iterate (fp32, large costs: the dual residual never settles below 100 tol); Optimal within 1e3 tol
+                n_flat = fabs(J - J_prev) <= (T)20 * Real<T>::eps() * fmax((T)1, fabs(J)) ? n_flat + 1 : 0;
+                J_prev = J;
+                if (n_flat >= 12 && err0 <= (T)1e3 * tol) { status = 0; break; }
                 const T mu_min = fmax(tol * (T)1e-2, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
                 for (; P.mu_strategy == 0;) {  // monotone barrier update (Ipopt default); mu_strategy 1 picks mu after the predictor
                     T cmu = 0;

@@ -1,6 +1,8 @@
 """Diagnostic: B=4096 N=20 fp64 launch time only (HIP events), for quick A/B of kernel changes."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mkz_mpc_path_follower_amd import _lib
+if os.environ.get("KMPC_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["KMPC_LIB"])  # A/B of diagnostic builds
 from mkz_mpc_path_follower_amd import BatchMPC
 from mkz_mpc_path_follower_amd.synthetic import make_batch
 N = int(os.environ.get("QN", 20)); B = int(os.environ.get("QB", 4096))

@@ -1,6 +1,8 @@
 """Diagnostic: mean / worst B=4096 launch time over several synthetic batches (different seeds), per horizon."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mkz_mpc_path_follower_amd import _lib
+if os.environ.get("KMPC_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["KMPC_LIB"])  # A/B of diagnostic builds
 from mkz_mpc_path_follower_amd import BatchMPC
 from mkz_mpc_path_follower_amd.synthetic import make_batch
 B = int(os.environ.get("QB", 4096))

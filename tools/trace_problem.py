@@ -1,0 +1,26 @@
+"""Diagnostic: per-iteration record of ONE problem of a synthetic batch on the GPU (needs `make -C mkz_mpc_path_follower_amd/csrc trace`).
+usage: trace_problem.py <index> [f32|f64] [N] [B]"""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mkz_mpc_path_follower_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "mkz_mpc_path_follower_amd", "libkmpc_hip_trace.so")
+from mkz_mpc_path_follower_amd import BatchMPC
+from mkz_mpc_path_follower_amd.synthetic import make_batch
+b = int(sys.argv[1]); f32 = (sys.argv[2] if len(sys.argv) > 2 else "f64") == "f32"
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 20; B = int(sys.argv[4]) if len(sys.argv) > 4 else 262144
+d = make_batch(B, N, cfg_id=2, dtype=np.float32 if f32 else np.float64)
+s = BatchMPC(N=N, dtype=torch.float32 if f32 else torch.float64)
+L = _lib.load()
+tr = torch.zeros((256, 8), dtype=torch.float64, device="cuda")
+L.kmpc_debug_set_stamps.argtypes = [C.c_void_p]
+L.kmpc_debug_set_stamps(C.c_void_p(tr.data_ptr()))
+o = s.solve(d["z0"][b:b + 1], d["ref"][b:b + 1], d["v_target"][b:b + 1], d["u_prev"][b:b + 1])
+torch.cuda.synchronize()
+t = tr.cpu().numpy(); it = int(o["iters"][0])
+print("problem", b, "status", int(o["status"][0]), "iters", it, "cost", float(o["cost"][0]), "viol", float(o["viol"][0]))
+print(" it        err0         rd       comp         mu               J      alpha  ls flags(exact,indef*2,corr*4,tiny*8)")
+for k in range(1, min(it, 255) + 1):
+    r = t[k]
+    print("%3d  %10.3e %10.3e %10.3e %10.3e %15.8f %10.3e %3d %3d" % (k, r[0], r[1], r[2], r[3], r[4], r[5], int(r[6]), int(r[7])))
