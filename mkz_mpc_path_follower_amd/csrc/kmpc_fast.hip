@@ -953,13 +953,13 @@ template <typename T, int N> struct FastSolver {
             STAMP(5);
             if (!factored) {
                 // Indefinite exact Hessian: strategy 0 -> Gauss-Newton for this and the next 2 iterations; 1 -> Ipopt's inertia
-                // correction K + delta_w*I, delta_w = 1e-4*max|sc*H_jj| (x100) the first time, last/3 (x8) afterwards;
+                // correction K + delta_w*I, delta_w = 1e-2*max|sc*H_jj| (x10) the first time, last/3 (x8) afterwards;
                 // 2 -> 0 until the second failure, 1 from then on (Gauss-Newton leaves a saddle only slowly)
                 if (++attempt >= 40) { status = 3; mode = FINAL; Ut = U; continue; }
                 if (use_exact && indef == 1) {
                     const T hmax = cs[C_HMAX], dw_last = cs[C_DWL];
-                    if (reg == (T)0) reg = dw_last > (T)0 ? fmax((T)1e-10 * hmax, dw_last / (T)3) : (T)1e-4 * hmax;
-                    else reg *= dw_last > (T)0 ? (T)8 : (T)100;
+                    if (reg == (T)0) reg = dw_last > (T)0 ? fmax((T)1e-10 * hmax, dw_last / (T)3) : (T)1e-2 * hmax;
+                    else reg *= dw_last > (T)0 ? (T)8 : (T)10;
                     if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; }
                 } else if (use_exact) {
                     use_exact = false; gn_hold = 2;

@@ -969,7 +969,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                 bool use_exact = exact && gn_hold == 0;  // GN is held for 2 iterations after an indefinite exact Hessian
                 if (gn_hold > 0) --gn_hold;
                 // Indefinite exact Hessian: indef_strategy 0 -> Gauss-Newton for this and the next 2 iterations;
-                // 1 -> Ipopt's inertia correction, K + delta_w*I with delta_w = 1e-4*max|sc*H_jj| (x100) the first time,
+                // 1 -> Ipopt's inertia correction, K + delta_w*I with delta_w = 1e-2*max|sc*H_jj| (x10) the first time,
                 // last/3 (x8) afterwards; the accumulators are kept, so a retry is one build_K + one factorisation.
                 // in shift mode the previous iteration's delta_w / 3 is the first trial (dropped below 1e-9 * max|H_jj|)
                 T reg = 0;
@@ -1003,8 +1003,8 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                     if (okc) { factored = true; if (use_exact && reg > 0) dw_last = reg; if (use_exact) dw_spec = reg; break; }
                     if (LDSACC) need_condense = true;  // the tiles lived in the matrix the factorisation just overwrote
                     if (use_exact && indef == 1) {
-                        if (reg == 0) reg = dw_last > 0 ? fmax((T)1e-10 * hmax, dw_last / 3) : (T)1e-4 * hmax;
-                        else reg *= dw_last > 0 ? (T)8 : (T)100;
+                        if (reg == 0) reg = dw_last > 0 ? fmax((T)1e-10 * hmax, dw_last / 3) : (T)1e-2 * hmax;
+                        else reg *= dw_last > 0 ? (T)8 : (T)10;
                         if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; need_condense = true; }
                     } else if (use_exact) {  // drop the second-order term
                         use_exact = false; gn_hold = 2; need_condense = true;

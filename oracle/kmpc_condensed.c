@@ -552,8 +552,9 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
         /* Indefinite exact Hessian (K not positive definite):
            indef_strategy 0: drop the second-order terms (Gauss-Newton) for this and the next gn_hold_k iterations
                              (a failed factorisation costs as much as a good one; N = 20: 11.1 -> 10.2 factorisations per solve);
-           indef_strategy 1: Ipopt's inertia correction -- shift the exact Hessian by delta_w*I, delta_w = 1e-4*max|H_jj| the first
-                             time (x100 on failure), later last/3 (x8 on failure); Gauss-Newton only if the shift exceeds 1e2*max|H_jj|.
+           indef_strategy 1: Ipopt's inertia correction -- shift the exact Hessian by delta_w*I, delta_w = 1e-2*max|H_jj| the first
+                             time (x10 on failure; Ipopt's 1e-4 / x100 lands 1-2 decades above what is needed and costs the slowest
+                             N = 20 problems ~10 % more work), later last/3 (x8 on failure); Gauss-Newton only if the shift exceeds 1e2*max|H_jj|.
            indef_strategy 2: hybrid -- 0 until the exact Hessian has failed gn_switch (2) times, then 1 for the rest of the solve
                              (Gauss-Newton ignores negative curvature and leaves a saddle only slowly: N = 20 worst case 63 -> 35).
            Short horizons do best with 2, long ones (N = 50: <= 28 iterations instead of 100-190) with 1. */
@@ -579,8 +580,8 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
             if (chol(K, n) == 0) { if (!use_gn && reg > 0.0) dw_last = reg; if (!use_gn) dw_spec = reg; break; }
             ++n_refac;
             if (!use_gn && indef_strategy == 1) {
-                if (reg == 0.0) reg = dw_last > 0.0 ? fmax(1e-10 * hmax, dw_last / 3.0) : 1e-4 * hmax;
-                else reg *= (dw_last > 0.0 ? 8.0 : 100.0);
+                if (reg == 0.0) reg = dw_last > 0.0 ? fmax(1e-10 * hmax, dw_last / 3.0) : 1e-2 * hmax;
+                else reg *= (dw_last > 0.0 ? 8.0 : 10.0);
                 if (reg > 1e2 * hmax) { use_gn = 1; reg = 0.0; }
             } else if (!use_gn) {
                 use_gn = 1; gn_hold = gn_hold_k;
