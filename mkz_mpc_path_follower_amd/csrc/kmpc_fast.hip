@@ -54,46 +54,75 @@ DEV float rsqrt_(float d) {
     return fmaf(y * e, fmaf(e, 0.375f, 0.5f), y);
 }
 
+// Polynomial coefficients.  An fp64 literal cannot be an instruction operand: LLVM materialises each one into a VGPR pair, hoists
+// that out of the iteration loop and keeps it there for the whole solve (~50 VGPRs at N = 20, with the excess spilled to scratch).
+// The fp64 kernels therefore read them from a small LDS table (uniform address: one broadcast pass, no VALU work); fp32 literals
+// are instruction operands and stay literals.
+enum { KC_S = 0, KC_C = 8, KC_2OPI = 16, KC_PIO2H, KC_PIO2L, KC_LG1, KC_LG2, KC_LG3, KC_LG4, KC_LG5, KC_LG6, KC_LG7, KC_LN2H, KC_LN2L,
+       KC_SQRTH, KC_COUNT = 32 };
+__constant__ const double kmpc_coef[KC_COUNT] = {
+    // sin: x + x^3 (S0 + z (S1 + ...)), listed from the highest power down (Horner order)
+    1.0 / 355687428096000.0, -1.0 / 1307674368000.0, 1.0 / 6227020800.0, -1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0,
+    // cos: 1 + z (-1/2 + z (C7 + ...)), Horner order; the -1/2 is an inline constant
+    -1.0 / 6402373705728000.0, 1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0, 1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0,
+    0.63661977236758134308, 1.57079632679489655800e+00, 6.12323399573676603587e-17,
+    // log (fdlibm e_log.c): Lg1..Lg7, ln2_hi, ln2_lo, sqrt(1/2)
+    6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01, 1.818357216161805012e-01,
+    1.531383769920937332e-01, 1.479819860511658591e-01, 6.93147180369123816490e-01, 1.90821492927058770002e-10, 0.70710678118654752440,
+    0.0, 0.0, 0.0 };
+template <typename T> struct Coef {  // fp32: literals
+    const T *tab;
+    DEV T operator[](int i) const { return (T)kmpc_coef[i]; }
+};
+template <> struct Coef<double> {    // fp64: LDS table
+    const double *tab;
+    DEV double operator[](int i) const { return tab[i]; }
+};
+
 // sin / cos for |x| <= 0.8 (tyre angles are bounded by steer_max <= 0.5 rad): Taylor to x^17 / x^18,
 // truncation < 2e-19 relative; larger arguments (non-default steer_max) take the libm path
-template <typename T> DEV void sincos_small(T x, T *s, T *c) {
+template <typename T> DEV void sincos_small(T x, T *s, T *c, Coef<T> kc) {
     if (fabs(x) > (T)0.8) { Real<T>::sincos_(x, s, c); return; }
     const T z = x * x;
-    T ps = (T)(1.0 / 355687428096000.0);
-    ps = fma(ps, z, (T)(-1.0 / 1307674368000.0));
-    ps = fma(ps, z, (T)(1.0 / 6227020800.0));
-    ps = fma(ps, z, (T)(-1.0 / 39916800.0));
-    ps = fma(ps, z, (T)(1.0 / 362880.0));
-    ps = fma(ps, z, (T)(-1.0 / 5040.0));
-    ps = fma(ps, z, (T)(1.0 / 120.0));
-    ps = fma(ps, z, (T)(-1.0 / 6.0));
+    T ps = kc[KC_S];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) ps = fma(ps, z, kc[KC_S + i]);
     *s = fma(x * z, ps, x);
-    T pc = (T)(-1.0 / 6402373705728000.0);
-    pc = fma(pc, z, (T)(1.0 / 20922789888000.0));
-    pc = fma(pc, z, (T)(-1.0 / 87178291200.0));
-    pc = fma(pc, z, (T)(1.0 / 479001600.0));
-    pc = fma(pc, z, (T)(-1.0 / 3628800.0));
-    pc = fma(pc, z, (T)(1.0 / 40320.0));
-    pc = fma(pc, z, (T)(-1.0 / 720.0));
-    pc = fma(pc, z, (T)(1.0 / 24.0));
+    T pc = kc[KC_C];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) pc = fma(pc, z, kc[KC_C + i]);
     pc = fma(pc, z, (T)(-0.5));
     *c = fma(z, pc, (T)1);
 }
 
 // sin / cos for |x| up to ~1e3 rad (headings are unwrapped relative to the reference, a few rad):
 // Cody-Waite reduction by pi/2 in two pieces + the same polynomials on |r| <= pi/4
-template <typename T> DEV void sincos_mid(T x, T *s, T *c) {
+template <typename T> DEV void sincos_mid(T x, T *s, T *c, Coef<T> kc) {
     if (!(fabs(x) < (T)1000)) { Real<T>::sincos_(x, s, c); return; }
-    const T k = rint(x * (T)0.63661977236758134308);
-    T r = fma(-k, (T)1.57079632679489655800e+00, x);
-    r = fma(-k, (T)6.12323399573676603587e-17, r);
+    const T k = rint(x * kc[KC_2OPI]);
+    T r = fma(-k, kc[KC_PIO2H], x);
+    r = fma(-k, kc[KC_PIO2L], r);
     T sr, cr;
-    sincos_small(r, &sr, &cr);
+    sincos_small(r, &sr, &cr, kc);
     const int q = (int)k & 3;
     const T ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
     *s = (q & 2) ? -ss : ss;
     *c = ((q + 1) & 2) ? -cc : cc;
 }
+
+// natural logarithm of a positive normal number (the slack products of the barrier function): fdlibm's e_log.c on the table, < 1 ulp
+DEV double log_pos(double x, Coef<double> kc) {
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);         // x = m 2^e, m in [1/2, 1)
+    const bool lo = m < kc[KC_SQRTH];
+    m = lo ? m + m : m; e = lo ? e - 1 : e;               // m in [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0, sq = f * rcp_(2.0 + f), z = sq * sq, w = z * z;
+    const double t1 = w * fma(w, fma(w, kc[KC_LG6], kc[KC_LG4]), kc[KC_LG2]);
+    const double t2 = z * fma(w, fma(w, fma(w, kc[KC_LG7], kc[KC_LG5]), kc[KC_LG3]), kc[KC_LG1]);
+    const double R = t1 + t2, hfsq = 0.5 * f * f, dk = (double)e;
+    return fma(dk, kc[KC_LN2H], -((hfsq - fma(sq, hfsq + R, dk * kc[KC_LN2L])) - f));
+}
+DEV float log_pos(float x, Coef<float>) { return logf(x); }
 
 template <typename T> struct StageF {  // lane k: state k / input k at the evaluated point
     T a, d, v, x, y, psi, c, s, sinb, cosb, b1, b2, ex, ey, ep, ev;
@@ -114,7 +143,7 @@ template <typename T, int N> struct FastSolver {
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
     static_assert(n + 1 <= 64 && n % 8 == 0, "fast kernel needs 2N + 1 <= 64 and N % 4 == 0");
     typedef typename Real<T>::acc_t acc_t;
-    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 64 + 2 * 64 * NF + 16 * (n / 4); }
+    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 64 + 2 * 64 * NF + 16 * (n / 4) + (sizeof(T) == 8 ? KC_COUNT : 0); }
     // start of column j minus j, so that element (row i, col j) lives at offc(j) + i
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
@@ -124,6 +153,7 @@ template <typename T, int N> struct FastSolver {
     int lane;  // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the
                // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
     T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *gb, *cub, *clb, *sinvb;
+    Coef<T> kc;  // polynomial coefficients (LDS table in fp64)
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
     T dt, dtc, rr_;
     T Cx2, Cy2, Cp2, Cv2, Cda2, Cdd2, Ca2, Cd2, dt2, dtL;  // 2*C_i, dt^2, dt/L_b from the host (KP: no scalar fp64 ALU on the device)
@@ -142,6 +172,8 @@ template <typename T, int N> struct FastSolver {
         cub = gb + 64; clb = cub + 64 * NF;  // corrector terms
         sinvb = clb + 64 * NF;  // D_j^-1 of the factor's 4x4 diagonal blocks (row-major, 16 per 4-column panel)
         for (int e = lane; e < 16 * (n / 4); e += 64) sinvb[e] = (T)0;
+        kc.tab = sinvb + 16 * (n / 4);
+        if (sizeof(T) == 8 && lane < KC_COUNT) const_cast<T *>(kc.tab)[lane] = (T)kmpc_coef[lane];
         dt = (T)p.dt; dtc = (T)p.dtc; rr_ = (T)p.r;
         Cx2 = (T)p.C2[0]; Cy2 = (T)p.C2[1]; Cp2 = (T)p.C2[2]; Cv2 = (T)p.C2[3];
         Cda2 = (T)p.C2[4]; Cdd2 = (T)p.C2[5]; Ca2 = (T)p.C2[6]; Cd2 = (T)p.C2[7];
@@ -270,7 +302,7 @@ template <typename T, int N> struct FastSolver {
         const T ia = dpp_scan_prefix<SROWS>(a);
         const T v = v0 + dt * (ia - a);
         T sd, cd;
-        sincos_small(d, &sd, &cd);
+        sincos_small(d, &sd, &cd, kc);
         const T Dn = cd * cd + rr_ * rr_ * sd * sd;
         const T rs = rsqrt_(Dn);
         S.sinb = rr_ * sd * rs;
@@ -282,7 +314,7 @@ template <typename T, int N> struct FastSolver {
         const T ip = dpp_scan_prefix<SROWS>(wp);
         const T psi = psi0 + dtL * (ip - wp);
         T sp, cp;
-        sincos_mid(psi, &sp, &cp);
+        sincos_mid(psi, &sp, &cp, kc);
         S.c = cp * S.cosb - sp * S.sinb;
         S.s = sp * S.cosb + cp * S.sinb;
         const T wx = st ? v * S.c : (T)0, wy = st ? v * S.s : (T)0;
@@ -799,9 +831,9 @@ template <typename T, int N> struct FastSolver {
                         const T a_ = sup[i] - alpha * aut[i], b_ = slo[i] + alpha * aut[i];
                         if (!(a_ > 0) || !(b_ > 0)) okp = false;
                         else if (sizeof(T) == 8) lpr *= a_ * b_;
-                        else lgt += log(a_ * b_);
+                        else lgt += log_pos(a_ * b_, kc);
                     }
-                if (sizeof(T) == 8) lgt = log(lpr);
+                if (sizeof(T) == 8) lgt = log_pos(lpr, kc);
                 okp = __all(okp);
                 const T slg = dpp_sum(lgt);
                 const T phi = sc * Jt - mu * slg;
@@ -856,7 +888,7 @@ template <typename T, int N> struct FastSolver {
                     {
                         T lg0 = 0;
 #pragma unroll
-                        for (int i = 0; i < NF; ++i) if (fv[i]) lg0 += log(sup[i] * slo[i]);
+                        for (int i = 0; i < NF; ++i) if (fv[i]) lg0 += log_pos(sup[i] * slo[i], kc);
                         cs[C_LGS] = dpp_sum(lg0);
                     }
                     const T gm = dpp_max(fabs(g));
