@@ -391,7 +391,7 @@ template <typename T, int N> struct FastSolver {
     // flight / on the matrix cores, the VALU advances the recursion to stage s+1.
     // The remaining second-order rows -- row rho = 2s+1 (d_f of stage s): mpd*G_psi + mvd*G_v, mdd on the diagonal -- are
     // written, scaled by sc, straight into the packed K image by the lane of each column; they define every ODD row of
-    // the image (build_K then adds to odd rows, stores even rows).
+    // the image (build_tiles reads them back into the C-layout tiles; nothing else of K goes through LDS).
     struct Rec { T a02, a03, a12, a13, a23, bx, by, bp, mpp, mpv, mpd, mvd, mdd; };
     DEV void load_rec(Rec &r, int s, T exs) const
     {
@@ -476,32 +476,19 @@ template <typename T, int N> struct FastSolver {
                 acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(S.fa[ti], S.fb[tj], acc[ti * (ti + 1) / 2 + tj]);
     }
 
-    // packed KKT image: lower triangle of sc*(H + input Hessian) + A^T W A + reg*I, and the rhs as row n.
+    // KKT tiles for the factorisation, built in registers: K = sc*(H + input Hessian) + A^T W A + reg*I in MFMA C-layout tiles (lower
+    // 16x16 tiles; the strict upper part of the diagonal tiles is never read), with the rhs -sc*g as row n.
     // Needs stage_form_weights(w) done (wb = form weights, cb = suffix sums of the speed weights).
-    // The dense part comes from the accumulators; A^T W A is structured: the speed rows add
-    // dt^2 * S[row/2] to every (even,even) entry -- (even,even) is a per-lane property in the MFMA C
-    // layout -- and the box / rate rows touch only the diagonal and the (j+2, j) entries, which lane j
-    // adds afterwards together with the input-cost Hessian (MKZMPCPathFollower.jl:99-102).
-    DEV void build_K(const acc_t (&acc)[NTT], T sc, T reg, T rhs)
+    // The dense part is the accumulators; A^T W A is structured: the speed rows add dt^2 * S[row/2] to every (even,even) entry --
+    // (even,even) is a per-lane property in the C layout -- and the box / rate rows touch only the diagonal and the (j+2, j)
+    // entries, which lane j computes together with the input-cost Hessian (MKZMPCPathFollower.jl:99-102) and hands over through
+    // a 2 x n staging buffer.  The second-order ODD rows come from the packed image, where condense put them.
+    static constexpr int NTF = (n + 1 + 15) / 16, NTTF = NTF * (NTF + 1) / 2;
+    // In place: on entry the first NTT tiles of kt are the accumulators of condense (same packed lower-triangular tile order).
+    DEV void build_tiles(T sc, T reg, acc_t (&kt)[NTTF])
     {
         const int c = lane & 15;
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * ti + Real<T>::row_of(lane, r);
-                const bool rowev = !(row & 1) && !(c & 1);
-                const T sp = rowev ? dt2 * cb[(row < n ? row : 0) >> 1] : (T)0;
-#pragma unroll
-                for (int tj = 0; tj <= ti; ++tj) {
-                    const int col = 16 * tj + c;
-                    const bool ok = row < n && col <= row;
-                    T *dst = ok ? Lc + offc_rt(ok ? col : 0) + row : xb + lane;
-                    const T v = sc * acc[ti * (ti + 1) / 2 + tj][r] + sp;
-                    *dst = (row & 1) ? *dst + v : v;  // odd rows already hold the second-order rows (condense)
-                }
-            }
-        WSYNC();
+        T *dgs = cub, *sbs = clb;  // the corrector buffers are dead between the accepted step and the end of the factorisation
         if (lane < n) {
             const int j = lane, jj = j & 1, k = j >> 1;
             const T Cu2 = jj ? Cd2 : Ca2, Cdl2 = jj ? Cdd2 : Cda2;
@@ -510,13 +497,43 @@ template <typename T, int N> struct FastSolver {
             if (j >= 4) dg += wb[n + j - 2];
             const bool rate = j >= 2 && j < R;
             const T wr = rate ? wb[n + j] : (T)0;
-            dg += wr;
-            T *pd = Lc + offc_rt(j);
-            pd[j] += dg;
-            if (j + 2 < n) pd[j + 2] += -wr - sc * Cdl2;
-            pd[n] = rhs;
+            dgs[j] = dg + wr;
+            sbs[j] = -wr - sc * Cdl2;
         }
         WSYNC();
+#pragma unroll
+        for (int tj = 0; tj < NTF; ++tj) {
+            const int col = 16 * tj + c;
+            const bool colok = col < n;
+            const int cs_ = colok ? col : 0;
+            const T dgv = dgs[cs_], sbv = sbs[cs_], rhv = -sc * gb[cs_];
+            const T *colK = Lc + offc_rt(cs_);
+#pragma unroll
+            for (int ti = tj; ti < NTF; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + Real<T>::row_of(lane, r);
+                    const bool oddrow = row & 1;
+                    T v = (T)0;
+                    if (ti < NT) {
+                        const bool evev = !oddrow && !(c & 1);
+                        const T sp = evev ? dt2 * cb[(row < n ? row : 0) >> 1] : (T)0;
+                        v = fma(sc, kt[ti * (ti + 1) / 2 + tj][r], sp);
+                        const bool rd = oddrow && row < n && col <= row;
+                        const T *src = rd ? colK + row : xb + lane;
+                        const T so = *src;
+                        v += rd ? so : (T)0;
+                        if (ti == tj) v += row == col ? dgv : (T)0;
+                        if (ti <= tj + 1) v += row == col + 2 ? sbv : (T)0;
+                    }
+                    v = row == n ? rhv : v;
+                    kt[ti * (ti + 1) / 2 + tj][r] = (colok && row <= n) ? v : (T)0;
+                }
+            // one tile column at a time: keeps the scheduler from stretching every tile's live range over the whole build
+#pragma unroll
+            for (int ti = tj; ti < NTF; ++ti) asm volatile("" : "+v"(kt[ti * (ti + 1) / 2 + tj]));
+        }
+        WFENCE();
     }
 
     // ---- blocked Cholesky on the matrix cores -----------------------------------------------------------------
@@ -529,7 +546,6 @@ template <typename T, int N> struct FastSolver {
     //   4. trailing tiles -= P P^T, one MFMA per live tile.
     // 2N/4 block-steps of ~170 instructions replace 2N rank-1 column steps; dead rows are zeroed in the fragments,
     // so finished entries are never touched again.
-    static constexpr int NTF = (n + 1 + 15) / 16, NTTF = NTF * (NTF + 1) / 2;
     template <int TJ> DEV bool chol_blocks(acc_t (&kt)[NTTF], int jb0, int jb1)
     {
         const int c = lane & 15, kk = lane >> 4;
@@ -611,24 +627,9 @@ template <typename T, int N> struct FastSolver {
         return true;
     }
 
-    DEV bool factor()
+    DEV bool factor(acc_t (&kt)[NTTF])
     {
         static_assert(n % 16 == 0 || n % 16 == 8, "block-steps are split at 16-column tile boundaries");
-        const int c = lane & 15;
-        acc_t kt[NTTF];
-#pragma unroll
-        for (int ti = 0; ti < NTF; ++ti)
-#pragma unroll
-            for (int tj = 0; tj <= ti; ++tj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + Real<T>::row_of(lane, r), col = 16 * tj + c;
-                    const int rr = row > col ? row : col, cc = row > col ? col : row;  // diagonal tiles are loaded symmetric
-                    const bool valid = rr <= n && cc < n;
-                    const T v = Lc[valid ? offc_rt(cc) + rr : 0];
-                    kt[ti * (ti + 1) / 2 + tj][r] = valid ? v : (T)0;
-                }
-        WFENCE();
         bool ok = chol_blocks<0>(kt, 0, (n < 16 ? n : 16) / 4);
         STAMP(12);
         if (NTF > 1 && n > 16) { if (ok) ok = chol_blocks<(NTF > 1 ? 1 : 0)>(kt, 4, (n < 32 ? n : 32) / 4); }
@@ -958,14 +959,14 @@ template <typename T, int N> struct FastSolver {
                 STAMP(2);
             }
             // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
-            const T rhs = -sc * gb[lane];
 #pragma unroll
             for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] * isu[i] + ll[i] * isl[i] : (T)0;
             stage_form_weights(w);
             STAMP(6);
             bool factored;
             {
-                acc_t acc[NTT];
+                acc_t kt[NTTF];  // condense accumulates into the first NTT tiles; build_tiles turns them into K in place
+                acc_t (&acc)[NTT] = reinterpret_cast<acc_t (&)[NTT]>(kt);
                 condense(use_exact, sc, acc);
                 if (use_exact && indef == 1 && first_attempt) {  // max |sc * H_jj| over the diagonal of the tiles: scale of the delta_w shift
                     T hm = 0;
@@ -978,10 +979,10 @@ template <typename T, int N> struct FastSolver {
                 }
                 first_attempt = false;
                 STAMP(3);
-                build_K(acc, sc, reg, rhs);
+                build_tiles(sc, reg, kt);
                 STAMP(4);
+                factored = factor(kt);
             }
-            factored = factor();
             STAMP(5);
             if (!factored) {
                 // Indefinite exact Hessian: strategy 0 -> Gauss-Newton for this and the next 2 iterations; 1 -> Ipopt's inertia
