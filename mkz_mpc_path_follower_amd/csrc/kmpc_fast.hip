@@ -412,12 +412,6 @@ template <typename T, int N> struct FastSolver {
         for (int s = s0; s < s1; ++s) {
             Rec nxt;
             load_rec(nxt, s + 1, exs);  // stage records are fetched one trip ahead: no LDS round trip on the recursion's path
-            // products of state s (fragments fetched one trip ago)
-#pragma unroll
-            for (int ti = 0; ti < ROWS; ++ti)
-#pragma unroll
-                for (int tj = 0; tj <= ti; ++tj)
-                    acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(S.fa[ti], S.fb[tj], acc[ti * (ti + 1) / 2 + tj]);
             // odd row rho = 2s+1 of the image from G_s (zero second-order part when !exact)
             const int rho = 2 * s + 1;
             const T val = sc * (S.cur.mpd * S.gp + S.cur.mvd * S.gv) + (lane == rho ? sc * S.cur.mdd : (T)0);
@@ -434,6 +428,14 @@ template <typename T, int N> struct FastSolver {
             S.gy = fma(ind, S.cur.by, S.gy);
             S.gp = fma(ind, S.cur.bp, S.gp);
             S.gv += isnew ? gvnew : (T)0;
+            // products of state s: its fragments were requested at the end of the previous trip and have landed while the recursion
+            // ran (the empty asm ties the first fragment to a recursion result, so the wait for them is not scheduled at the loop top)
+            if (ROWS > 0) asm volatile("" : "+v"(S.fa[0]), "+v"(S.gx));
+#pragma unroll
+            for (int ti = 0; ti < ROWS; ++ti)
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj)
+                    acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(S.fa[ti], S.fb[tj], acc[ti * (ti + 1) / 2 + tj]);
             // weights of state s+1: 2Q_{s+1} + M_{s+1}^{psi,v}
             const T Cv1 = s + 1 <= N - 1 ? Cv2 : (T)0;
             // component-major staging: opb[comp][col]
