@@ -408,7 +408,7 @@ template <typename T, int N> struct FastSolver {
         const T pef = (lane & 1) ? (T)1 : (T)0;      // d_f columns take B's steering column, acc columns (0,0,0,dt)
         const T gvnew = (lane & 1) ? (T)0 : dt;
         T *colK = Lc + offc_rt(lane < n ? lane : 0);  // column `lane` of the packed K image
-#pragma nounroll
+#pragma unroll 2
         for (int s = s0; s < s1; ++s) {
             Rec nxt;
             load_rec(nxt, s + 1, exs);  // stage records are fetched one trip ahead: no LDS round trip on the recursion's path
@@ -451,7 +451,9 @@ template <typename T, int N> struct FastSolver {
             pin(nxt.mpp); pin(nxt.mpv); pin(nxt.mpd); pin(nxt.mvd); pin(nxt.mdd);
             // fragments of state s+1 (the registers were consumed by the MFMAs at the top)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { S.fa[t] = opb[kk * 64 + 16 * t + c]; S.fb[t] = opb[(4 + kk) * 64 + 16 * t + c]; }
+            for (int t = 0; t < (ROWS + 1 < NT ? ROWS + 1 : NT); ++t) {  // the next trip has at most one more live tile row
+                S.fa[t] = opb[kk * 64 + 16 * t + c]; S.fb[t] = opb[(4 + kk) * 64 + 16 * t + c];
+            }
             S.cur = nxt;
         }
     }
