@@ -155,8 +155,13 @@ template <typename T, int N> struct FastSolver {
     T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *gb, *cub, *clb, *sinvb;
     Coef<T> kc;  // polynomial coefficients (LDS table in fp64)
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
-    T dt, dtc, rr_;
-    T Cx2, Cy2, Cp2, Cv2, Cda2, Cdd2, Ca2, Cd2, dt2, dtL;  // 2*C_i, dt^2, dt/L_b from the host (KP: no scalar fp64 ALU on the device)
+    // Kernel-argument scalars (model constants, limits, tolerances, the doubled weights 2*C_i, products like dt^2 that the host
+    // computed because there is no scalar fp64 ALU) are copied once into an LDS table, pt = cb + 32 (cb holds N <= 28 suffix sums), and
+    // read from there: the kernarg segment arrives as 16-SGPR tuples which the allocator spills and then reloads WHOLE at every use
+    // of any member (~600 v_readlane per iteration before this table).
+    enum { PT_DT = 0, PT_DTC, PT_RR, PT_DT2, PT_DTL, PT_LB, PT_TOL, PT_GAP_TOL, PT_TOL_X100, PT_TOL_X1000, PT_TOL_D100, PT_TOL_D10,
+           PT_STEER_MAX, PT_A_MAX, PT_STEER_DMAX, PT_A_DMAX, PT_W = 16, PT_V_MIN = 24, PT_V_MAX, PT_RELAX, PT_WARM_PUSH, PT_WARM_MU, PT_MU_INIT };
+    const T *pt, *cwt;
 
     DEV FastSolver(const KP &p, unsigned char *smem) : P(p), lane(threadIdx.x)
     {
@@ -174,10 +179,18 @@ template <typename T, int N> struct FastSolver {
         for (int e = lane; e < 16 * (n / 4); e += 64) sinvb[e] = (T)0;
         kc.tab = sinvb + 16 * (n / 4);
         if (sizeof(T) == 8 && lane < KC_COUNT) const_cast<T *>(kc.tab)[lane] = (T)kmpc_coef[lane];
-        dt = (T)p.dt; dtc = (T)p.dtc; rr_ = (T)p.r;
-        Cx2 = (T)p.C2[0]; Cy2 = (T)p.C2[1]; Cp2 = (T)p.C2[2]; Cv2 = (T)p.C2[3];
-        Cda2 = (T)p.C2[4]; Cdd2 = (T)p.C2[5]; Ca2 = (T)p.C2[6]; Cd2 = (T)p.C2[7];
-        dt2 = (T)p.dt2; dtL = (T)p.dt_over_Lb;
+        pt = cb + 32; cwt = pt + PT_W;
+        if (lane == 0) {
+            T *q = cb + 32;
+            q[PT_DT] = (T)p.dt; q[PT_DTC] = (T)p.dtc; q[PT_RR] = (T)p.r; q[PT_DT2] = (T)p.dt2; q[PT_DTL] = (T)p.dt_over_Lb; q[PT_LB] = (T)p.L_b;
+            q[PT_TOL] = (T)p.tol; q[PT_GAP_TOL] = (T)p.gap_tol; q[PT_TOL_X100] = (T)p.tol_x100; q[PT_TOL_X1000] = (T)p.tol_x1000;
+            q[PT_TOL_D100] = (T)p.tol_d100; q[PT_TOL_D10] = (T)p.tol_d10;
+            q[PT_STEER_MAX] = (T)p.steer_max; q[PT_A_MAX] = (T)p.a_max; q[PT_STEER_DMAX] = (T)p.steer_dmax; q[PT_A_DMAX] = (T)p.a_dmax;
+            q[PT_W + 0] = (T)p.C2[0]; q[PT_W + 1] = (T)p.C2[1]; q[PT_W + 2] = (T)p.C2[2]; q[PT_W + 3] = (T)p.C2[3];
+            q[PT_W + 4] = (T)p.C2[4]; q[PT_W + 5] = (T)p.C2[5]; q[PT_W + 6] = (T)p.C2[6]; q[PT_W + 7] = (T)p.C2[7];
+            q[PT_V_MIN] = (T)p.v_min; q[PT_V_MAX] = (T)p.v_max; q[PT_RELAX] = (T)p.relax; q[PT_WARM_PUSH] = (T)p.warm_push;
+            q[PT_WARM_MU] = (T)p.warm_mu; q[PT_MU_INIT] = (T)p.mu_init;
+        }
     }
 
     DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)
@@ -198,26 +211,27 @@ template <typename T, int N> struct FastSolver {
 
     DEV void form_bounds(int f, T &bu, T &bl) const
     {
-        const T relax = (T)P.relax;
+        const T relax = pt[PT_RELAX];
         if (f < n) {
-            const T ub = (f & 1) ? (T)P.steer_max : (T)P.a_max;
+            const T ub = pt[(f & 1) ? PT_STEER_MAX : PT_A_MAX];
             bu = bl = ub + relax * fmax((T)1, ub);
         } else if (f < n + R) {
             const int r = f - n, jj = r & 1, kk = r >> 1;
-            const T d = (jj ? (T)P.steer_dmax : (T)P.a_dmax) * (kk == 0 ? dtc : dt);
+            const T d = pt[jj ? PT_STEER_DMAX : PT_A_DMAX] * pt[kk == 0 ? PT_DTC : PT_DT];
             const T u = kk == 0 ? (jj ? up1 : up0) : (T)0;
             bu = d + relax * fmax((T)1, d) + u; bl = d + relax * fmax((T)1, d) - u;
         } else if (f < nf) {
-            bu = (T)P.v_max + relax * fmax((T)1, fabs((T)P.v_max)) - v0;
-            bl = -(T)P.v_min + relax * fmax((T)1, fabs((T)P.v_min)) + v0;
+            const T vmax = pt[PT_V_MAX], vmin = pt[PT_V_MIN];
+            bu = vmax + relax * fmax((T)1, fabs(vmax)) - v0;
+            bl = -vmin + relax * fmax((T)1, fabs(vmin)) + v0;
         } else { bu = bl = (T)1; }
     }
     DEV T form_relax(int f, bool upper) const
     {
-        const T relax = (T)P.relax;
-        if (f < n) return relax * fmax((T)1, (f & 1) ? (T)P.steer_max : (T)P.a_max);
-        if (f < n + R) { const int r = f - n; return relax * fmax((T)1, ((r & 1) ? (T)P.steer_dmax : (T)P.a_dmax) * ((r >> 1) == 0 ? dtc : dt)); }
-        return relax * fmax((T)1, fabs(upper ? (T)P.v_max : (T)P.v_min));
+        const T relax = pt[PT_RELAX];
+        if (f < n) return relax * fmax((T)1, pt[(f & 1) ? PT_STEER_MAX : PT_A_MAX]);
+        if (f < n + R) { const int r = f - n; return relax * fmax((T)1, pt[(r & 1) ? PT_STEER_DMAX : PT_A_DMAX] * pt[(r >> 1) == 0 ? PT_DTC : PT_DT]); }
+        return relax * fmax((T)1, fabs(pt[upper ? PT_V_MAX : PT_V_MIN]));
     }
 
     // y_f = a_f^T x   (x: lane j holds x_j)
@@ -235,7 +249,7 @@ template <typename T, int N> struct FastSolver {
             T v = (T)0;
             if (f < n) v = xb[f];
             else if (f < n + R) { const int r = f - n; v = r < 2 ? xb[r] : xb[r + 2] - xb[r]; }
-            else if (f < nf) v = dt * cb[f - n - R];
+            else if (f < nf) v = pt[PT_DT] * cb[f - n - R];
             y[i] = v;
         }
         WSYNC();
@@ -260,7 +274,7 @@ template <typename T, int N> struct FastSolver {
             if (j < 2) o += wb[n + j];
             if (j >= 4) o += wb[n + j - 2];
             if (j >= 2 && j < R) o -= wb[n + j];
-            if (!(j & 1)) o += dt * cb[j >> 1];
+            if (!(j & 1)) o += pt[PT_DT] * cb[j >> 1];
         }
         WSYNC();
         return o;
@@ -276,13 +290,13 @@ template <typename T, int N> struct FastSolver {
         } else if (row == col + 2 && col >= 2 && col < R) {
             g = -wb[n + col];
         }
-        if (!((row | col) & 1)) g += dt2 * cb[row >> 1];
+        if (!((row | col) & 1)) g += pt[PT_DT2] * cb[row >> 1];
         return g;
     }
     DEV T input_hess(int row, int col) const
     {
         const int jj = row & 1, k = row >> 1;
-        const T Cu2 = jj ? Cd2 : Ca2, Cdl2 = jj ? Cdd2 : Cda2;
+        const T Cu2 = cwt[jj ? 7 : 6], Cdl2 = cwt[jj ? 5 : 4];
         if (row == col) return Cu2 + Cdl2 * (T)((k > 0) + (k < N - 1));
         if (row == col + 2) return -Cdl2;
         return (T)0;
@@ -291,6 +305,7 @@ template <typename T, int N> struct FastSolver {
     // roll-out (MKZMPCPathFollower.jl:115-122 as prefix scans) + objective (:97-103) at U (lane j: U_j)
     DEV T eval(T U, StageF<T> &S)
     {
+        const T dt = pt[PT_DT], rr_ = pt[PT_RR], dtL = pt[PT_DTL];
         if (lane < n) xb[lane] = U;
         WSYNC();
         const int k = lane;
@@ -328,6 +343,7 @@ template <typename T, int N> struct FastSolver {
         S.ep = cs ? psi - rp : (T)0;
         S.ev = (k >= 1 && k <= N - 1) ? v - vt : (T)0;
         // (the weights are held doubled -- the form every derivative needs; halving the sum is exact)
+        const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3], Cda2 = cwt[4], Cdd2 = cwt[5], Ca2 = cwt[6], Cd2 = cwt[7];
         T Jl = Cx2 * S.ex * S.ex + Cy2 * S.ey * S.ey + Cp2 * S.ep * S.ep + Cv2 * S.ev * S.ev;
         if (st) Jl += Ca2 * a * a + Cd2 * d * d;
         if (k < N - 1) Jl += Cda2 * (an - a) * (an - a) + Cdd2 * (dn - d) * (dn - d);
@@ -338,8 +354,10 @@ template <typename T, int N> struct FastSolver {
     // costates by suffix scans -> gradient (returned, lane j: g_j); per-stage scalars go to LDS (Lc alias)
     DEV T linearize(const StageF<T> &S, bool exact)
     {
+        const T dt = pt[PT_DT], dtL = pt[PT_DTL];
         const int k = lane;
         const bool st = k < N;
+        const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3], Cda2 = cwt[4], Cdd2 = cwt[5], Ca2 = cwt[6], Cd2 = cwt[7];
         const T lx = Cx2 * S.ex, ly = Cy2 * S.ey, lp = Cp2 * S.ep, lv = Cv2 * S.ev;
         const T px = dpp_scan_suffix<SROWS>(lx, lane), py = dpp_scan_suffix<SROWS>(ly, lane);
         const T px1 = dpp_mov0<0x130, 0xf>(px), py1 = dpp_mov0<0x130, 0xf>(py);  // wave_shl:1 -> value of lane+1
@@ -406,8 +424,9 @@ template <typename T, int N> struct FastSolver {
     {
         const int kk = lane >> 4, c = lane & 15;
         const T pef = (lane & 1) ? (T)1 : (T)0;      // d_f columns take B's steering column, acc columns (0,0,0,dt)
-        const T gvnew = (lane & 1) ? (T)0 : dt;
+        const T gvnew = (lane & 1) ? (T)0 : pt[PT_DT];
         T *colK = Lc + offc_rt(lane < n ? lane : 0);  // column `lane` of the packed K image
+        const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3];
 #pragma unroll 2
         for (int s = s0; s < s1; ++s) {
             Rec nxt;
@@ -492,10 +511,11 @@ template <typename T, int N> struct FastSolver {
     DEV void build_tiles(T sc, T reg, acc_t (&kt)[NTTF])
     {
         const int c = lane & 15;
+        const T dt2 = pt[PT_DT2];
         T *dgs = cub, *sbs = clb;  // the corrector buffers are dead between the accepted step and the end of the factorisation
         if (lane < n) {
             const int j = lane, jj = j & 1, k = j >> 1;
-            const T Cu2 = jj ? Cd2 : Ca2, Cdl2 = jj ? Cdd2 : Cda2;
+            const T Cu2 = cwt[jj ? 7 : 6], Cdl2 = cwt[jj ? 5 : 4];
             T dg = wb[j] + sc * (Cu2 + Cdl2 * (T)((k > 0) + (k < N - 1))) + reg;
             if (j < 2) dg += wb[n + j];
             if (j >= 4) dg += wb[n + j - 2];
@@ -704,11 +724,13 @@ template <typename T, int N> struct FastSolver {
 
     DEV bool interior_point(T &Uf)
     {
-        const T relax = (T)P.relax;
+        const T relax = pt[PT_RELAX], dt = pt[PT_DT], dtc = pt[PT_DTC];
+        const T steer_max = pt[PT_STEER_MAX], a_max = pt[PT_A_MAX], steer_dmax = pt[PT_STEER_DMAX], a_dmax = pt[PT_A_DMAX];
+        const T v_min = pt[PT_V_MIN], v_max = pt[PT_V_MAX];
         // first guess of the solution inside the bounds (same rule as the CPU checker): accelerations approach
         // the reference speed (time constant 1 s), steering the kinematic feed-forward of the reference's mean curvature;
         // reference points 1..N only -- point 0 is a dead input (Q3)
-        const T frac = (T)0.6, rr = (T)P.r;
+        const T frac = (T)0.6, rr = pt[PT_RR];
         T len, kap;
         {
             const T rxn = __shfl_down(rx, 1), ryn = __shfl_down(ry, 1);
@@ -717,37 +739,37 @@ template <typename T, int N> struct FastSolver {
             kap = (readlane_(rp, N) - readlane_(rp, 1)) / fmax(len, (T)1e-6);
         }
         const T vref = len / ((T)(N - 1) * dt);
-        const T sb = fmin(fmax((T)P.L_b * kap, (T)-0.9), (T)0.9);
-        const T dff = fmin(fmax(atan(tan(asin(sb)) / rr), -frac * (T)P.steer_max), frac * (T)P.steer_max);
-        const T aff = fmin(fmax(vref - v0, -frac * (T)P.a_max), frac * (T)P.a_max);
+        const T sb = fmin(fmax(pt[PT_LB] * kap, (T)-0.9), (T)0.9);
+        const T dff = fmin(fmax(atan(tan(asin(sb)) / rr), -frac * steer_max), frac * steer_max);
+        const T aff = fmin(fmax(vref - v0, -frac * a_max), frac * a_max);
         T u0[2];
         // Q5: v[1] = v0 is itself bounded in the reference model -> any v0 outside the (relaxed) speed bounds is infeasible
-        bool ok = v0 >= (T)P.v_min - relax * fmax((T)1, fabs((T)P.v_min)) && v0 <= (T)P.v_max + relax * fmax((T)1, fabs((T)P.v_max));
+        bool ok = v0 >= v_min - relax * fmax((T)1, fabs(v_min)) && v0 <= v_max + relax * fmax((T)1, fabs(v_max));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const T ub = j ? (T)P.steer_max : (T)P.a_max;
-            const T d0 = (j ? (T)P.steer_dmax : (T)P.a_dmax) * dtc;
+            const T ub = j ? steer_max : a_max;
+            const T d0 = (j ? steer_dmax : a_dmax) * dtc;
             const T up = j ? up1 : up0;
             T lo = fmax(-ub - relax * fmax((T)1, ub), up - d0 - relax * fmax((T)1, d0));
             T hi = fmin(ub + relax * fmax((T)1, ub), up + d0 + relax * fmax((T)1, d0));
             if (j == 0) {
-                lo = fmax(lo, ((T)P.v_min - relax * fmax((T)1, fabs((T)P.v_min)) - v0) / dt);
-                hi = fmin(hi, ((T)P.v_max + relax * fmax((T)1, fabs((T)P.v_max)) - v0) / dt);
+                lo = fmax(lo, (v_min - relax * fmax((T)1, fabs(v_min)) - v0) / dt);
+                hi = fmin(hi, (v_max + relax * fmax((T)1, fabs(v_max)) - v0) / dt);
             }
             if (!(lo < hi)) ok = false;
             const T push = (T)0.25 * (hi - lo);
             u0[j] = fmin(fmax(j ? dff : aff, lo + push), hi - push);
         }
-        const T vm = fmin((T)1, (T)0.25 * ((T)P.v_max - (T)P.v_min)), acap = (T)0.5 * (T)P.a_max;
-        const T astep = frac * (T)P.a_dmax * dt, dstep = frac * (T)P.steer_dmax * dt;
+        const T vm = fmin((T)1, (T)0.25 * (v_max - v_min)), acap = (T)0.5 * a_max;
+        const T astep = frac * a_dmax * dt, dstep = frac * steer_dmax * dt;
         T v = v0 + dt * u0[0], ap = u0[0], dp = u0[1];
         Uf = lane == 0 ? u0[0] : (lane == 1 ? u0[1] : (T)0);
 #pragma nounroll
         for (int k = 1; k < N; ++k) {  // uniform scalar recurrence
-            T a = fmin(fmax(vref - v, -frac * (T)P.a_max), frac * (T)P.a_max);
+            T a = fmin(fmax(vref - v, -frac * a_max), frac * a_max);
             a = fmin(fmax(a, ap - astep), ap + astep);
-            if (v + dt * a < (T)P.v_min + vm) a = fmin((T)P.v_min + vm - v, acap);
-            else if (v + dt * a > (T)P.v_max - vm) a = fmax((T)P.v_max - vm - v, -acap);
+            if (v + dt * a < v_min + vm) a = fmin(v_min + vm - v, acap);
+            else if (v + dt * a > v_max - vm) a = fmax(v_max - vm - v, -acap);
             const T d = fmin(fmax(dff, dp - dstep), dp + dstep);
             if (lane == 2 * k) Uf = a;
             if (lane == 2 * k + 1) Uf = d;
@@ -763,7 +785,9 @@ template <typename T, int N> struct FastSolver {
     DEV void solve(const KIO<T> &io, int b)
     {
         const T kappa_eps = 10, kappa_mu = (T)0.2, tau_min = (T)0.99, kappa_sigma = (T)1e10, eta_phi = (T)1e-8, s_max = 100;
-        const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
+        // the integer options are copied out of the kernel arguments once (the argument tuple is not touched inside the loop)
+        const int max_ls = P.max_ls, max_iter = P.max_iter, indef_cfg = P.indef_strategy;
+        const bool warm = P.warm != 0;
         const bool exact = P.hessian == 1;
         T U, Ut, du = 0;
         // slacks are iterates, advanced by s -/+ alpha * a_f^T du (as in Ipopt): recomputing b - a_f^T U would lose 7 digits to
@@ -775,9 +799,9 @@ template <typename T, int N> struct FastSolver {
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
         enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J, C_LGS, C_JP };
         cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_AD] = 0; cs[C_J] = 0; cs[C_JP] = (T)1e30;
-        int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
+        int indef = indef_cfg == 2 ? 0 : indef_cfg, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
         bool have_best = false;
-        T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, Jt = 0, alpha = 0, reg = 0;
+        T mu = pt[warm ? PT_WARM_MU : PT_MU_INIT], sc = 1, Jt = 0, alpha = 0, reg = 0;
         bool use_exact = exact;
         enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3, RESTEP = 4 };
         const bool pc = P.mu_strategy == 1;
@@ -794,10 +818,10 @@ template <typename T, int N> struct FastSolver {
             const bool feas = interior_point(Uf);
             if (!feas) {
                 status = 2;
-                const T ub = (lane & 1) ? (T)P.steer_max : (T)P.a_max;
+                const T ub = pt[(lane & 1) ? PT_STEER_MAX : PT_A_MAX];
                 U = lane < n ? fmin(fmax((lane & 1) ? up1 : up0, -ub), ub) : (T)0;
                 mode = FINAL;
-            } else if (P.warm && io.warmU) {
+            } else if (warm && io.warmU) {
                 const T dw = lane < n ? io.warmU[(size_t)b * n + lane] - Uf : (T)0;
                 forms_apply(Uf, w);
                 forms_apply(dw, aut);
@@ -810,7 +834,7 @@ template <typename T, int N> struct FastSolver {
                         if (aut[i] > 0) th = fmin(th, (bu_ - w[i]) / aut[i]);
                         if (aut[i] < 0) th = fmin(th, (bl_ + w[i]) / -aut[i]);
                     }
-                th = dpp_min(th) * ((T)1 - (T)P.warm_push);
+                th = dpp_min(th) * ((T)1 - pt[PT_WARM_PUSH]);
                 U = Uf + th * dw;
             } else U = Uf;
         }
@@ -819,7 +843,7 @@ template <typename T, int N> struct FastSolver {
 #pragma nounroll
         for (;;) {
             asm volatile("" : "+v"(lane));
-            if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && cs[C_ERR] <= tol)) {
+            if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && cs[C_ERR] <= pt[PT_TOL])) {
                 // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
                 Ut = ubest[lane]; U = Ut; status = 0;
             }
@@ -846,8 +870,8 @@ template <typename T, int N> struct FastSolver {
                 if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * cs[C_DPHI])) {
                     // safeguard: the corrected direction is tried at the full step only; redo the step without the corrector term
                     if (corr_active) { mode = RESTEP; Ut = U; continue; }
-                    if (++ls >= P.max_ls) {
-                        status = cs[C_ERR] <= (T)P.tol_x100 ? 0 : 3; mode = FINAL; Ut = U; continue;  // acceptable level
+                    if (++ls >= max_ls) {
+                        status = cs[C_ERR] <= pt[PT_TOL_X100] ? 0 : 3; mode = FINAL; Ut = U; continue;  // acceptable level
                     }
                     alpha *= (T)0.5;
                     Ut = U + alpha * du;
@@ -858,7 +882,7 @@ template <typename T, int N> struct FastSolver {
                 {
                     const T stepn = dpp_max(fabs(alpha * du)), umax = fmax((T)1, dpp_max(fabs(U)));
                     n_tiny = stepn <= (T)10 * Real<T>::eps() * umax ? n_tiny + 1 : 0;
-                    if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= (T)P.tol_x1000 ? 0 : 3; tiny_stop = true; mode = FINAL; continue; }
+                    if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= pt[PT_TOL_X1000] ? 0 : 3; tiny_stop = true; mode = FINAL; continue; }
                 }
                 // accepted: dual step from the pre-step slacks, then the slacks advance with the step
                 cs[C_LGS] = slg;  // = sum log(slack) of the new iterate: the next barrier value re-uses it
@@ -908,7 +932,7 @@ template <typename T, int N> struct FastSolver {
                             ll[i] = fmax(fmin(ll[i], kappa_sigma * mu * isl[i]), mu * isl[i] * ((T)1 / kappa_sigma));
                         }
                 }
-                if (iters >= P.max_iter) { mode = FINAL; Ut = U; continue; }  // status stays ITERATION_LIMIT
+                if (iters >= max_iter) { mode = FINAL; Ut = U; continue; }  // status stays ITERATION_LIMIT
                 ++iters;
                 // optimality error (Ipopt's scaled test + unscaled duality-gap bound)
 #pragma unroll
@@ -926,7 +950,8 @@ template <typename T, int N> struct FastSolver {
                 constexpr T inv2nf = (T)1 / (T)(2 * nf);
                 const T isd = s_max * rcp_(fmax(s_max, lsum * inv2nf));  // 1 / s_d
                 const T err0 = fmax(rdm, cm0) * isd;
-                const T gap_lim = gap_tol * fmax((T)1, fabs(Jt));
+                const T tol = pt[PT_TOL];
+                const T gap_lim = pt[PT_GAP_TOL] * fmax((T)1, fabs(Jt));
                 cs[C_ERR] = err0; cs[C_RDS] = rdm * isd;
                 TRACE8(io.stamps, iters, err0, rdm * isd, cm0 * isd, mu, Jt, alpha, ls, (use_exact ? 1 : 0) + 2 * indef + 4 * (int)corr_active + 8 * n_tiny);
                 // Ipopt's test (+ gap bound, pursued for at most 1 more iteration once Ipopt's test is met), or
@@ -936,14 +961,14 @@ template <typename T, int N> struct FastSolver {
                 if (err0 <= tol) {
                     if (gap <= gap_lim * sc || n_polish >= 1) done = true; else ++n_polish;
                 } else if (n_polish > 0 && ++n_polish > 1) done = true;
-                n_accept = err0 <= (T)P.tol_x100 ? n_accept + 1 : 0;
+                n_accept = err0 <= pt[PT_TOL_X100] ? n_accept + 1 : 0;
                 // rounding floor: the objective has not moved by more than 20 eps |J| for 12 iterations in a row -> the arithmetic cannot
                 // improve the iterate (fp32, large costs: the dual residual never settles below 100 tol); Optimal within 1e3 tol
                 n_flat = fabs(Jt - cs[C_JP]) <= (T)20 * Real<T>::eps() * fmax((T)1, fabs(Jt)) ? n_flat + 1 : 0;
                 cs[C_JP] = Jt;
-                if (n_flat >= 12 && err0 <= (T)P.tol_x1000) done = true;
+                if (n_flat >= 12 && err0 <= pt[PT_TOL_X1000]) done = true;
                 if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
-                const T mu_min = fmax((T)P.tol_d100, fmin((T)P.tol_d10, (T)0.1 * gap_lim * sc * inv2nf));
+                const T mu_min = fmax(pt[PT_TOL_D100], fmin(pt[PT_TOL_D10], (T)0.1 * gap_lim * sc * inv2nf));
                 cs[C_MUF] = mu_min;
 #pragma nounroll
                 for (; !pc;) {  // monotone barrier update (mu_strategy 0)
@@ -1000,7 +1025,7 @@ template <typename T, int N> struct FastSolver {
                     if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; }
                 } else if (use_exact) {
                     use_exact = false; gn_hold = 2;
-                    if (P.indef_strategy == 2 && ++n_fail >= 2) { indef = 1; gn_hold = 0; }
+                    if (indef_cfg == 2 && ++n_fail >= 2) { indef = 1; gn_hold = 0; }
                 } else reg = reg == (T)0 ? (T)1e-8 : reg * (T)100;  // last resort: shift the Gauss-Newton matrix
                 mode = REFACTOR; Ut = U;
                 continue;
