@@ -125,13 +125,34 @@ template <int ROWS, typename T> DEV T dpp_scan_suffix(T x, int lane) {
     }
     return v;
 }
-template <typename T> DEV T dpp_sum(T x) { return readlane_(dpp_scan_prefix<4>(x), 63); }
-template <typename T> DEV T dpp_max(T x) {
+template <typename T> DEV T dpp_sum(T x) {  // wave-wide sum, returned uniform (a reduction tree: one DPP step fewer than the scan)
+    T v = x + dpp_mov0<0x111, 0xf>(x);
+    v += dpp_mov0<0x112, 0xf>(v);
+    v += dpp_mov0<0x114, 0xf>(v);
+    v += dpp_mov0<0x118, 0xf>(v);   // lane 15 of each row: the row's sum
+    v += dpp_mov0<0x142, 0xa>(v);
+    v += dpp_mov0<0x143, 0xc>(v);
+    return readlane_(v, 63);
+}
+// max without the canonicalising v_max(x, x) the compiler puts in front of fmax() for operands that are raw bit moves (DPP / readlane)
+DEV double max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int CTRL, int RM> DEV double dpp_mov_keep_rows(double x, double ident) {  // as dpp_mov_keep, rows outside RM keep `ident`
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(x), CTRL, RM, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(x), CTRL, RM, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int RM> DEV float dpp_mov_keep_rows(float x, float ident) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(x), CTRL, RM, 0xf, false));
+}
+template <typename T> DEV T dpp_max(T x) {  // wave-wide maximum, returned uniform (NaN operands are dropped, as by fmax)
     const T ninf = -INFINITY;
-    x = fmax(x, dpp_mov_keep<0x111>(x, ninf));
-    x = fmax(x, dpp_mov_keep<0x112>(x, ninf));
-    x = fmax(x, dpp_mov_keep<0x114>(x, ninf));
-    x = fmax(x, dpp_mov_keep<0x118>(x, ninf));
-    return fmax(fmax(readlane_(x, 15), readlane_(x, 31)), fmax(readlane_(x, 47), readlane_(x, 63)));
+    x = max_raw(x, dpp_mov_keep<0x111>(x, ninf));
+    x = max_raw(x, dpp_mov_keep<0x112>(x, ninf));
+    x = max_raw(x, dpp_mov_keep<0x114>(x, ninf));
+    x = max_raw(x, dpp_mov_keep<0x118>(x, ninf));            // lane 15 of each row: the row's maximum
+    x = max_raw(x, dpp_mov_keep_rows<0x142, 0xa>(x, ninf));  // row_bcast15 into rows 1 and 3
+    x = max_raw(x, dpp_mov_keep_rows<0x143, 0xc>(x, ninf));  // row_bcast31 into rows 2 and 3: lane 63 holds the maximum
+    return readlane_(x, 63);
 }
 template <typename T> DEV T dpp_min(T x) { return -dpp_max(-x); }
