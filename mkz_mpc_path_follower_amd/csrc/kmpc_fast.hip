@@ -537,21 +537,25 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + Real<T>::row_of(lane, r);
-                    const bool oddrow = row & 1;
+                    const bool oddrow = row & 1;  // fp64 C layout: a property of the lane; fp32: of the register index
+                    // boundary conditions are spelled per tile position so that interior tiles carry no selects for them
                     T v = (T)0;
                     if (ti < NT) {
-                        const bool evev = !oddrow && !(c & 1);
-                        const T sp = evev ? dt2 * cb[(row < n ? row : 0) >> 1] : (T)0;
-                        v = fma(sc, kt[ti * (ti + 1) / 2 + tj][r], sp);
-                        const bool rd = oddrow && row < n && col <= row;
-                        const T *src = rd ? colK + row : xb + lane;
-                        const T so = *src;
-                        v += rd ? so : (T)0;
+                        const T evm = (!oddrow && !(c & 1)) ? dt2 : (T)0;
+                        v = fma(sc, kt[ti * (ti + 1) / 2 + tj][r], evm * cb[(ti == NTF - 1 ? (row < n ? row : 0) : row) >> 1]);
+                        bool rd = oddrow;
+                        if (ti == NTF - 1) rd = rd && row < n;
+                        if (ti == tj) rd = rd && col <= row;
+                        if (tj == NTF - 1) rd = rd && colok;
+                        const T *src = rd ? colK + row : pt;  // pt[0] is finite: the product with the zero mask below is exact
+                        const T odm = rd ? (T)1 : (T)0;
+                        v = fma(odm, *src, v);
                         if (ti == tj) v += row == col ? dgv : (T)0;
                         if (ti <= tj + 1) v += row == col + 2 ? sbv : (T)0;
                     }
-                    v = row == n ? rhv : v;
-                    kt[ti * (ti + 1) / 2 + tj][r] = (colok && row <= n) ? v : (T)0;
+                    if (ti == NTF - 1) { v = row == n ? rhv : v; v = row <= n ? v : (T)0; }
+                    if (tj == NTF - 1) v = colok ? v : (T)0;
+                    kt[ti * (ti + 1) / 2 + tj][r] = v;
                 }
             // one tile column at a time: keeps the scheduler from stretching every tile's live range over the whole build
 #pragma unroll
