@@ -155,4 +155,13 @@ template <typename T> DEV T dpp_max(T x) {  // wave-wide maximum, returned unifo
     x = max_raw(x, dpp_mov_keep_rows<0x143, 0xc>(x, ninf));  // row_bcast31 into rows 2 and 3: lane 63 holds the maximum
     return readlane_(x, 63);
 }
+template <typename T> DEV T dpp_max_nn(T x) {  // wave-wide maximum of NON-NEGATIVE values: zero fill instead of a -inf identity (no moves to set it up)
+    x = max_raw(x, dpp_mov0<0x111, 0xf>(x));
+    x = max_raw(x, dpp_mov0<0x112, 0xf>(x));
+    x = max_raw(x, dpp_mov0<0x114, 0xf>(x));
+    x = max_raw(x, dpp_mov0<0x118, 0xf>(x));
+    x = max_raw(x, dpp_mov0<0x142, 0xa>(x));
+    x = max_raw(x, dpp_mov0<0x143, 0xc>(x));
+    return readlane_(x, 63);
+}
 template <typename T> DEV T dpp_min(T x) { return -dpp_max(-x); }

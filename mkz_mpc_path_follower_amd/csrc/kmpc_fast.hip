@@ -582,14 +582,14 @@ template <typename T, int N> struct FastSolver {
         for (int jb = jb0; jb < jb1; ++jb) {
             const int j0 = 4 * jb, kp = c - (j0 & 15);
             const bool holder = kp >= 0 && kp < 4;
+            if (holder) {  // one exec-masked region instead of an address select per store
+                T *dst = pan + 4 * Real<T>::row_of(lane, 0) + kp;
 #pragma unroll
-            for (int ti = TJ; ti < NTF; ++ti)
+                for (int ti = TJ; ti < NTF; ++ti)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + Real<T>::row_of(lane, r);
-                    T *dst = holder ? pan + 4 * row + kp : xb + lane;
-                    *dst = kt[ti * (ti + 1) / 2 + TJ][r];
-                }
+                    for (int r = 0; r < 4; ++r)
+                        dst[4 * (16 * ti + Real<T>::row_of(0, r))] = kt[ti * (ti + 1) / 2 + TJ][r];
+            }
             WFENCE();
             const T *pd = pan + 4 * j0;
             const T d00 = pd[0], d10 = pd[4], d11 = pd[5], d20 = pd[8], d21 = pd[9], d22 = pd[10];
@@ -637,8 +637,7 @@ template <typename T, int N> struct FastSolver {
                 const T xs = kk == 0 ? x0 : (kk == 1 ? x1 : (kk == 2 ? x2 : x3));
                 const bool live = row >= jc && row <= n;
                 pf[t] = live ? xs : (T)0;                       // component kk of L (MFMA fragment of the trailing update)
-                T *dst = live ? colL + row : xb + lane;
-                *dst = fma(x3, c3, fma(x2, c2, fma(x1, c1, x0 * c0)));  // component kk of L~ = L D^-1
+                if (live) colL[row] = fma(x3, c3, fma(x2, c2, fma(x1, c1, x0 * c0)));  // component kk of L~ = L D^-1
             }
             if (j0 + 4 < n) {
                 const int tmin = (j0 + 4) >> 4;  // first tile column that still has live entries
@@ -884,7 +883,7 @@ template <typename T, int N> struct FastSolver {
                 // Ipopt's tiny-step rule: two accepted steps in a row below 10 eps relative to the iterate -> the arithmetic cannot improve
                 // it; Optimal if the error is within 1e3 tol (where the rounding floor of the fp32 dual residual sits), else Error
                 {
-                    const T stepn = dpp_max(fabs(alpha * du)), umax = fmax((T)1, dpp_max(fabs(U)));
+                    const T stepn = dpp_max_nn(fabs(alpha * du)), umax = fmax((T)1, dpp_max_nn(fabs(U)));
                     n_tiny = stepn <= (T)10 * Real<T>::eps() * umax ? n_tiny + 1 : 0;
                     if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= pt[PT_TOL_X1000] ? 0 : 3; tiny_stop = true; mode = FINAL; continue; }
                 }
@@ -924,7 +923,7 @@ template <typename T, int N> struct FastSolver {
                         for (int i = 0; i < NF; ++i) if (fv[i]) lg0 += log_pos(sup[i] * slo[i], kc);
                         cs[C_LGS] = dpp_sum(lg0);
                     }
-                    const T gm = dpp_max(fabs(g));
+                    const T gm = dpp_max_nn(fabs(g));
                     sc = gm > (T)100 ? (T)100 / gm : (T)1;  // Ipopt nlp_scaling_max_gradient
 #pragma unroll
                     for (int i = 0; i < NF; ++i) { lu[i] = mu * isu[i]; ll[i] = mu * isl[i]; }
@@ -949,8 +948,8 @@ template <typename T, int N> struct FastSolver {
                         const T cu = sup[i] * lu[i], cl = slo[i] * ll[i];
                         lsum += lu[i] + ll[i]; gap += cu + cl; cm0 = fmax(cm0, fmax(cu, cl));
                     }
-                const T rdm = dpp_max(fabs(rd));
-                lsum = dpp_sum(lsum); cm0 = dpp_max(cm0); gap = dpp_sum(gap);
+                const T rdm = dpp_max_nn(fabs(rd));
+                lsum = dpp_sum(lsum); cm0 = dpp_max_nn(cm0); gap = dpp_sum(gap);
                 constexpr T inv2nf = (T)1 / (T)(2 * nf);
                 const T isd = s_max * rcp_(fmax(s_max, lsum * inv2nf));  // 1 / s_d
                 const T err0 = fmax(rdm, cm0) * isd;
@@ -980,7 +979,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                     for (int i = 0; i < NF; ++i)
                         if (fv[i]) cmu = fmax(cmu, fmax(fabs(sup[i] * lu[i] - mu), fabs(slo[i] * ll[i] - mu)));
-                    cmu = dpp_max(cmu);
+                    cmu = dpp_max_nn(cmu);
                     if (fmax(rdm, cmu) * isd <= kappa_eps * mu && mu > mu_min) mu = fmax(mu_min, fmin(kappa_mu * mu, mu * sqrt(mu)));
                     else break;
                 }
@@ -1008,7 +1007,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[ti * (ti + 1) / 2 + ti][r]));
-                    cs[C_HMAX] = dpp_max(hm);
+                    cs[C_HMAX] = dpp_max_nn(hm);
                 }
                 first_attempt = false;
                 STAMP(3);
@@ -1054,7 +1053,7 @@ template <typename T, int N> struct FastSolver {
                         rda = fmax(rda, fmax((T)1 - qu, (T)1 + ql));
                         mucur += sup[i] * lu[i] + slo[i] * ll[i];
                     }
-                const T apa = rcp_(dpp_max(rpa)), ada = rcp_(dpp_max(rda));
+                const T apa = rcp_(dpp_max_nn(rpa)), ada = rcp_(dpp_max_nn(rda));
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     if (fv[i]) {
@@ -1094,8 +1093,8 @@ template <typename T, int N> struct FastSolver {
                     rq = fmax(rq, fmax(-dlu * rcp_(lu[i]), -dll * rcp_(ll[i])));
                 }
             // fraction to the boundary: alpha = min(1, tau * min(-s/ds)) = tau / max(tau, max(-ds/s))
-            const T ap = tau * rcp_(fmax(tau, dpp_max(rp)));
-            cs[C_AD] = tau * rcp_(fmax(tau, dpp_max(rq)));
+            const T ap = tau * rcp_(fmax(tau, dpp_max_nn(rp)));
+            cs[C_AD] = tau * rcp_(fmax(tau, dpp_max_nn(rq)));
             cs[C_PHI0] = sc * cs[C_J] - mu * cs[C_LGS];
             cs[C_DPHI] = dpp_sum((lane < n ? sc * gb[lane] * du : (T)0) + gw);  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
             alpha = ap; ls = 0;
