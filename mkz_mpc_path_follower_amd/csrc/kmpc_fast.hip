@@ -10,18 +10,22 @@
 //     call site (the iteration is a small state machine: a line-search trial and the next
 //     iterate's evaluation are the same code).
 //   * INSTRUCTION COUNT.  With the chip full the kernel is VALU-issue-bound (SQ counters in
-//     profiles/): ~8 k instructions per iteration at 4 issue cycles each.
+//     profiles/): ~4.6 k VALU instructions per iteration at 4 issue cycles each.  Things that cost
+//     instructions without doing arithmetic, found in the opcode histogram of the loop: SGPR-spill
+//     reloads of the kernel-argument tuples (-> scalars read from an LDS table), fp64 literals parked
+//     in VGPRs (-> LDS coefficient table), canonicalising v_max in front of fmax on DPP results
+//     (-> raw v_max), selects (-> 0/1 masks, exec-masked regions), IEEE divisions (-> rcp + Newton);
 //   * no ds_bpermute / LDS round trips for scans and reductions: DPP row_shr / row_shl / row_bcast;
 //   * condensing: the sensitivity recursion runs once per column (lane j = column j), its MFMA
 //     fragments are staged through a small LDS buffer, v_mfma_f64_16x16x4_f64 accumulates lower
-//     16x16 tiles; the tiles are written once, with the barrier terms, into a packed column-major
-//     LDS image (n(n+3)/2 words, 6.9 KB at N = 20, rhs as row n);
+//     16x16 tiles; the KKT matrix is completed IN those registers (barrier terms, shift, rhs row);
 //   * Cholesky: 4-column panels on the matrix cores (the 4x4 diagonal block redundantly in every
-//     lane, panel rows in MFMA fragment layout, one MFMA per trailing tile); what is stored is the
-//     block-LDL^T form L~ = L D^-1, so the substitutions are n/4 dependent block steps and the
-//     rhs row comes out solved through L~ and D;
+//     lane, panel rows in MFMA fragment layout, one MFMA per trailing tile); what is stored (packed
+//     column-major LDS image, n(n+3)/2 words, 6.9 KB at N = 20) is the block-LDL^T form L~ = L D^-1,
+//     so the substitutions are n/4 dependent block steps and the rhs row comes out solved through L~ and D;
 //   * wave-uniform scalars that are read once or twice per iteration, the best iterate, the
-//     gradient and the corrector terms live in LDS, not in VGPRs (2 waves per SIMD = 256 VGPRs).
+//     gradient and the corrector terms live in LDS, not in VGPRs (2 waves per SIMD = 256 VGPRs,
+//     20 KB of LDS per wave = exactly 8 waves per CU at N = 20).
 #include "kmpc_common.h"
 
 #define WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
@@ -279,29 +283,6 @@ template <typename T, int N> struct FastSolver {
         WSYNC();
         return o;
     }
-    DEV T gram_entry(int row, int col) const
-    {
-        T g = (T)0;
-        if (row == col) {
-            g = wb[row];
-            if (row < 2) g += wb[n + row];
-            if (row >= 4) g += wb[n + row - 2];
-            if (row >= 2 && row < R) g += wb[n + row];
-        } else if (row == col + 2 && col >= 2 && col < R) {
-            g = -wb[n + col];
-        }
-        if (!((row | col) & 1)) g += pt[PT_DT2] * cb[row >> 1];
-        return g;
-    }
-    DEV T input_hess(int row, int col) const
-    {
-        const int jj = row & 1, k = row >> 1;
-        const T Cu2 = cwt[jj ? 7 : 6], Cdl2 = cwt[jj ? 5 : 4];
-        if (row == col) return Cu2 + Cdl2 * (T)((k > 0) + (k < N - 1));
-        if (row == col + 2) return -Cdl2;
-        return (T)0;
-    }
-
     // roll-out (MKZMPCPathFollower.jl:115-122 as prefix scans) + objective (:97-103) at U (lane j: U_j)
     DEV T eval(T U, StageF<T> &S)
     {
