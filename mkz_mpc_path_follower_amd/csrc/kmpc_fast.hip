@@ -1123,9 +1123,10 @@ template <typename T, int N> struct FastSolver {
 
 // waves per SIMD: the fp64 kernel needs ~250 VGPRs to run without scratch spills (measured: at 128 VGPRs the
 // spills moved 1.6 GB of HBM traffic per 4096-problem launch against 2.4 MB of algorithmic bytes); the kernel is
-// issue-bound, not occupancy-bound, so 2 waves/SIMD without spills beats 4 with.  fp32 fits 3 waves spill-free.
+// issue-bound, not occupancy-bound, so 2 waves/SIMD without spills beats 4 with.  fp32 fits 4 waves spill-free up to N = 20 (128 VGPRs; +10 % over 3
+// waves at N = 16 / 20) and 3 waves beyond.
 template <typename T, int N>
-__global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : 3) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N>::lds_elems() * sizeof(T)];
     if ((int)blockIdx.x >= P.B) return;
