@@ -188,6 +188,7 @@ template <typename T, int N> struct FastSolver {
         for (int e = lane; e < 16 * (n / 4); e += 64) sinvb[e] = (T)0;
         kc.tab = sinvb + 16 * (n / 4);
         if (sizeof(T) == 8 && lane < KC_COUNT) const_cast<T *>(kc.tab)[lane] = (T)kmpc_coef[lane];
+        static_assert(N <= 32, "the scalar table shares the 64-entry cb buffer with the N suffix sums");
         pt = cb + 32; cwt = pt + PT_W;
         if (lane == 0) {
             T *q = cb + 32;
