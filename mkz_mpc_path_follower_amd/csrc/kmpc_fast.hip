@@ -606,11 +606,11 @@ template <typename T, int N> struct FastSolver {
                 T *sq = sinvb + 16 * jb;
                 sq[0] = r0; sq[4] = i10; sq[5] = r1; sq[8] = i20; sq[9] = i21; sq[10] = r2; sq[12] = i30; sq[13] = i31; sq[14] = i32; sq[15] = r3;
             }
-            // column kk of inv, for this lane's component of L~
-            const T c0 = kk == 0 ? r0 : (T)0;
-            const T c1 = kk == 0 ? i10 : (kk == 1 ? r1 : (T)0);
-            const T c2 = kk == 0 ? i20 : (kk == 1 ? i21 : (kk == 2 ? r2 : (T)0));
-            const T c3 = kk == 0 ? i30 : (kk == 1 ? i31 : (kk == 2 ? i32 : r3));
+            // column kk of inv, for this lane's component of L~: read back from the block just stored (4 LDS reads instead of 9 selects;
+            // they feed only the L~ stores, which are off the panel -> MFMA critical path)
+            WFENCE();
+            const T *sqc = sinvb + 16 * jb + kk;
+            const T c0 = sqc[0], c1 = sqc[4], c2 = sqc[8], c3 = sqc[12];
             T pf[NTF];
             const int jc = j0 + kk;
             T *colL = Lc + offc_rt(jc < n ? jc : 0);
