@@ -6,7 +6,8 @@
 
 A "step" is one pass of the hot path (kmpc_solve_batch) over one batch of synthetic (x0, path
 segment) problems already resident in HBM, followed -- for N > 1 -- by the all-gather of the
-(accel, steer) blocks.  Workload at every N: BASELINE.json configs[1], batch = 4096 problems per
+(accel, steer) blocks (RCCL; asynchronous and double-buffered, so the exchange of batch k overlaps the
+solve of batch k+1 -- every gather completes inside the timed region).  Workload at every N: BASELINE.json configs[1], batch = 4096 problems per
 GPU, horizon 20, fp64 (weak scaling: the batch is sharded, per-GPU work is fixed).
 Prints ONE JSON line on rank 0.
 """
@@ -165,7 +166,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mkz_mpc_path_follower_amd import BatchMPC
-    from mkz_mpc_path_follower_amd.dist import all_gather_solutions
+    from mkz_mpc_path_follower_amd.dist import SolutionGather
     from mkz_mpc_path_follower_amd.synthetic import make_batch
 
     N, Bl = a.horizon, a.batch
@@ -176,26 +177,32 @@ def main():
     d = make_batch(Bl, N, cfg_id=2, seed=20180620 + 2 + 1000 * rank)
     din = {k: torch.as_tensor(d[k], dtype=tdt, device=dev) for k in ("z0", "ref", "v_target", "u_prev")}
     solver = BatchMPC(N=N, dtype=tdt, device=local)
-    out = None
+    # N > 1: the all-gather of batch k's (accel, steer) block runs asynchronously on the collective's stream while batch k+1 is
+    # solved; two output slots alternate, and a slot's gather is waited for before a solve may overwrite the buffer it reads.
+    # Every step's gather completes inside the timed region (final waits + synchronize below).
+    gather = SolutionGather(B)
+    outs = [None, None]
 
-    def step():
-        nonlocal out
-        out = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=out)
-        return all_gather_solutions(out["u0"], B) if world > 1 else out["u0"]
-
-    for _ in range(a.warmup):
-        step()
+    for i in range(a.warmup):
+        s = i & 1
+        gather.wait(s)
+        outs[s] = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=outs[s])
+        gather.submit(s, outs[s]["u0"])
+    gather.wait(0); gather.wait(1)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
+        s = i & 1
+        gather.wait(s)
         ev[i][0].record()   # same stream the kernel is launched on (torch's current stream is handed to the C ABI)
-        out = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=out)
+        outs[s] = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=outs[s])
         ev[i][1].record()
-        if world > 1:
-            all_gather_solutions(out["u0"], B)
+        gather.submit(s, outs[s]["u0"])
+    gather.wait(0); gather.wait(1)
+    out = outs[(a.steps - 1) & 1]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -32,3 +32,37 @@ def all_gather_solutions(u0_local, B, group=None):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+class SolutionGather:
+    """Double-buffered, asynchronous all-gather of the (accel, steer) blocks for a stream of batches.
+
+    `submit(slot, u0_local)` starts the gather of one batch on the collective's own stream (RCCL: the copy engines / xGMI run it
+    while the next batch's solve kernel computes); `wait(slot)` makes the current stream wait for it and returns the [B, 2]
+    result.  The caller alternates two slots and must `wait(slot)` before it lets a solve overwrite the `u0_local` buffer that
+    slot's gather reads -- `bench.py` does exactly that, so a step's solution exchange costs no time on the solve stream.
+    Equal shards only (the ragged case uses `all_gather_solutions`)."""
+
+    def __init__(self, B, group=None, slots=2, force_collective=False):
+        self.B, self.group = B, group
+        self.force = force_collective  # run the collective even in a 1-rank group (exercises the RCCL path on one GPU)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if self.world > 1 and B % self.world:
+            raise ValueError("SolutionGather needs equal shards (B %% world == 0)")
+        self.work = [None] * slots
+        self.out = [None] * slots
+
+    def submit(self, slot, u0_local):
+        if self.world == 1 and not self.force:
+            self.out[slot] = u0_local
+            return
+        if self.out[slot] is None or self.out[slot].dtype != u0_local.dtype or self.out[slot].device != u0_local.device:
+            self.out[slot] = torch.empty((self.B, 2), dtype=u0_local.dtype, device=u0_local.device)
+        self.work[slot] = dist.all_gather_into_tensor(self.out[slot], u0_local.contiguous(), group=self.group, async_op=True)
+
+    def wait(self, slot):
+        w = self.work[slot]
+        if w is not None:
+            w.wait()
+            self.work[slot] = None
+        return self.out[slot]

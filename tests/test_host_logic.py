@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from mkz_mpc_path_follower_amd.dist import all_gather_solutions, shard_range
+from mkz_mpc_path_follower_amd.dist import SolutionGather, all_gather_solutions, shard_range
 from mkz_mpc_path_follower_amd.messages import MPCCmd, MPCPath, StateEst
 from mkz_mpc_path_follower_amd.node import MPCNode
 from mkz_mpc_path_follower_amd.synthetic import make_batch, straight_line_case
@@ -117,6 +117,47 @@ def test_all_gather_of_solution_shards_gloo_world2(B):
     for p in ps:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _pipeline_worker(rank, world, port, B, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(B, rank, world)
+    g = SolutionGather(B)
+    local = [torch.zeros((hi - lo, 2), dtype=torch.float64) for _ in range(2)]
+    ok = True
+    for step in range(5):  # the loop of bench.py: wait(slot) before the slot's source buffer is overwritten, then submit
+        s = step & 1
+        prev = g.wait(s)
+        if step >= 2:
+            ok = ok and bool(torch.equal(prev, torch.arange(B * 2, dtype=torch.float64).reshape(B, 2) + 1000.0 * (step - 2)))
+        full = torch.arange(B * 2, dtype=torch.float64).reshape(B, 2) + 1000.0 * step
+        local[s].copy_(full[lo:hi])
+        g.submit(s, local[s])
+    for step in (3, 4):
+        ok = ok and bool(torch.equal(g.wait(step & 1), torch.arange(B * 2, dtype=torch.float64).reshape(B, 2) + 1000.0 * step))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_pipelined_solution_gather_gloo_world2():
+    """bench.py's N>1 loop: the gather of batch k (async, double-buffered) overlaps the solve of batch k+1; every batch's
+    gathered block must still be the right one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 8, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+    g = SolutionGather(6)  # single process: pass-through
+    u = torch.ones((6, 2))
+    g.submit(0, u)
+    assert g.wait(0) is u
 
 
 def test_ros_adapter_topic_surface():
