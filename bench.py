@@ -154,16 +154,23 @@ def main():
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank control flow on a one-GPU box)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.backend == "gloo":
+        local = local % torch.cuda.device_count()  # rehearsal: the ranks share the box's GPU(s)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from mkz_mpc_path_follower_amd import BatchMPC
     from mkz_mpc_path_follower_amd.dist import SolutionGather
