@@ -76,7 +76,7 @@ typedef struct kmpc_config {
                                delta_w shift of the exact Hessian, 2 = hybrid (0 until the second failure of a solve, 1 from then on);
                                2 is the default */
     int32_t schedule;       /* order in which the problems of a batch start on the GPU: 0 = index order, 1 (default) = longest
-                               predicted first (key = |v0 - reference speed| + 1.33 * total heading change of the reference), which
+                               predicted first (key = |v0 - reference speed| + 0.3 * net heading change of the reference), which
                                shortens the tail of a launch whose time is set by its slowest problems.  Results do not depend on it.
                                Calls on one handle must be stream-ordered (the permutation workspace belongs to the handle). */
     int32_t model;          /* 0 (default) = MKZMPCPathFollower.jl, Cartesian states (x, y, psi, v); 1 = MKZMPCPathFollowerFrenet.jl,
