@@ -398,16 +398,16 @@ template <typename T, int N> struct FastSolver {
     // written, scaled by sc, straight into the packed K image by the lane of each column; they define every ODD row of
     // the image (build_tiles reads them back into the C-layout tiles; nothing else of K goes through LDS).
     struct Rec { T a02, a03, a12, a13, a23, bx, by, bp, mpp, mpv, mpd, mvd, mdd; };
-    DEV void load_rec(Rec &r, int s, T exs) const
+    DEV void load_rec(Rec &r, int s) const
     {
         const T *q = lin + LIN_STRIDE * s;  // record N is all zero (linearize)
         r.a02 = q[0]; r.a03 = q[1]; r.a12 = q[2]; r.a13 = q[3]; r.a23 = q[4]; r.bx = q[5]; r.by = q[6]; r.bp = q[7];
-        r.mpp = exs * q[8]; r.mpv = exs * q[9]; r.mpd = exs * q[10]; r.mvd = exs * q[11]; r.mdd = exs * q[12];
+        r.mpp = q[8]; r.mpv = q[9]; r.mpd = q[10]; r.mvd = q[11]; r.mdd = q[12];  // zero when the Gauss-Newton matrix is wanted
     }
     struct CondState { T gx, gy, gp, gv, fa[NT], fb[NT]; Rec cur; };
     // Trips [s0, s1) of the stage loop with a FIXED number of live tile rows (ROWS = tile rows that hold columns < 2s), so the body
     // is one basic block: the products of state s are issued first and run on the matrix cores in the shadow of the recursion work.
-    template <int ROWS> DEV void condense_trips(int s0, int s1, CondState &S, acc_t (&acc)[NTT], T sc, T exs)
+    template <int ROWS> DEV void condense_trips(int s0, int s1, CondState &S, acc_t (&acc)[NTT], T sc)
     {
         const int kk = lane >> 4, c = lane & 15;
         const T pef = (lane & 1) ? (T)1 : (T)0;      // d_f columns take B's steering column, acc columns (0,0,0,dt)
@@ -417,7 +417,7 @@ template <typename T, int N> struct FastSolver {
 #pragma unroll 2
         for (int s = s0; s < s1; ++s) {
             Rec nxt;
-            load_rec(nxt, s + 1, exs);  // stage records are fetched one trip ahead: no LDS round trip on the recursion's path
+            load_rec(nxt, s + 1);  // stage records are fetched one trip ahead: no LDS round trip on the recursion's path
             // odd row rho = 2s+1 of the image from G_s (zero second-order part when !exact)
             const int rho = 2 * s + 1;
             const T val = sc * (S.cur.mpd * S.gp + S.cur.mvd * S.gv) + (lane == rho ? sc * S.cur.mdd : (T)0);
@@ -463,22 +463,28 @@ template <typename T, int N> struct FastSolver {
             S.cur = nxt;
         }
     }
-    DEV void condense(bool exact, T sc, acc_t (&acc)[NTT])
+    // The second-order entries of the stage records decide between the exact and the Gauss-Newton matrix: linearize writes them only
+    // when the exact Hessian is wanted, and a fallback inside an iteration clears them (drop_second_order).
+    DEV void drop_second_order()
+    {
+        if (lane <= N) { T *q = lin + LIN_STRIDE * lane; q[8] = q[9] = q[10] = q[11] = q[12] = (T)0; }
+        WSYNC();
+    }
+    DEV void condense(T sc, acc_t (&acc)[NTT])
     {
 #pragma unroll
         for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
-        const T exs = exact ? (T)1 : (T)0;
         CondState S;
         S.gx = S.gy = S.gp = S.gv = (T)0;            // column `lane` of G at the current state
 #pragma unroll
         for (int t = 0; t < NT; ++t) S.fa[t] = S.fb[t] = (T)0;  // MFMA fragments of the state whose products are still to be issued
-        load_rec(S.cur, 0, exs);
+        load_rec(S.cur, 0);
         // trip s multiplies state s, whose columns 0..2s-1 live in ceil(2s/16) tile rows
-        condense_trips<0>(0, 1, S, acc, sc, exs);
-        condense_trips<1>(1, N < 9 ? N : 9, S, acc, sc, exs);
-        if (NT >= 2 && N > 9) condense_trips<(NT >= 2 ? 2 : 1)>(9, N < 17 ? N : 17, S, acc, sc, exs);
-        if (NT >= 3 && N > 17) condense_trips<(NT >= 3 ? 3 : 1)>(17, N < 25 ? N : 25, S, acc, sc, exs);
-        if (NT >= 4 && N > 25) condense_trips<(NT >= 4 ? 4 : 1)>(25, N, S, acc, sc, exs);
+        condense_trips<0>(0, 1, S, acc, sc);
+        condense_trips<1>(1, N < 9 ? N : 9, S, acc, sc);
+        if (NT >= 2 && N > 9) condense_trips<(NT >= 2 ? 2 : 1)>(9, N < 17 ? N : 17, S, acc, sc);
+        if (NT >= 3 && N > 17) condense_trips<(NT >= 3 ? 3 : 1)>(17, N < 25 ? N : 25, S, acc, sc);
+        if (NT >= 4 && N > 25) condense_trips<(NT >= 4 ? 4 : 1)>(25, N, S, acc, sc);
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -892,7 +898,7 @@ template <typename T, int N> struct FastSolver {
             if (!restep) {
             if (mode != REFACTOR) {
             U = Ut; cs[C_J] = Jt;
-            const T g = linearize(St, exact);
+            const T g = linearize(St, exact && gn_hold == 0);  // = use_exact of this iteration (set below, before gn_hold counts down)
             gb[lane] = g;
             STAMP(1);
                 if (mode == FIRST) {
@@ -986,7 +992,7 @@ template <typename T, int N> struct FastSolver {
             {
                 acc_t kt[NTTF];  // condense accumulates into the first NTT tiles; build_tiles turns them into K in place
                 acc_t (&acc)[NTT] = reinterpret_cast<acc_t (&)[NTT]>(kt);
-                condense(use_exact, sc, acc);
+                condense(sc, acc);
                 if (use_exact && indef == 1 && first_attempt) {  // max |sc * H_jj| over the diagonal of the tiles: scale of the delta_w shift
                     T hm = 0;
 #pragma unroll
@@ -1012,9 +1018,9 @@ template <typename T, int N> struct FastSolver {
                     const T hmax = cs[C_HMAX], dw_last = cs[C_DWL];
                     if (reg == (T)0) reg = dw_last > (T)0 ? fmax((T)1e-10 * hmax, dw_last / (T)3) : (T)1e-2 * hmax;
                     else reg *= dw_last > (T)0 ? (T)8 : (T)10;
-                    if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; }
+                    if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; drop_second_order(); }
                 } else if (use_exact) {
-                    use_exact = false; gn_hold = 2;
+                    use_exact = false; gn_hold = 2; drop_second_order();
                     if (indef_cfg == 2 && ++n_fail >= 2) { indef = 1; gn_hold = 0; }
                 } else reg = reg == (T)0 ? (T)1e-8 : reg * (T)100;  // last resort: shift the Gauss-Newton matrix
                 mode = REFACTOR; Ut = U;
