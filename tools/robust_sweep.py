@@ -9,7 +9,7 @@ from mkz_mpc_path_follower_amd.synthetic import make_batch
 B = int(os.environ.get("QB", 262144))
 for N in [int(x) for x in os.environ.get("QNS", "8,12,16,20,24,28").split(",")]:
     for dt in ("f64", "f32"):
-        d = make_batch(B, N, cfg_id=2, dtype=np.float64 if dt == "f64" else np.float32)
+        d = make_batch(B, N, cfg_id=int(os.environ.get("QCFG", 2)), dtype=np.float64 if dt == "f64" else np.float32)
         s = BatchMPC(N=N, dtype=torch.float64 if dt == "f64" else torch.float32)
         dev = {k: torch.as_tensor(d[k], device="cuda") for k in ("z0", "ref", "v_target", "u_prev")}
         o = s.solve(dev["z0"], dev["ref"], dev["v_target"], dev["u_prev"])
