@@ -851,13 +851,15 @@ template <typename T, int N> struct FastSolver {
                 T lgt = 0, lpr = 1;
                 bool okp = true;
 #pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        const T a_ = sup[i] - alpha * aut[i], b_ = slo[i] + alpha * aut[i];
-                        if (!(a_ > 0) || !(b_ > 0)) okp = false;
-                        else if (sizeof(T) == 8) lpr *= a_ * b_;
-                        else lgt += log_pos(a_ * b_, kc);
-                    }
+                // (no validity guard: the unused forms of the last register carry s = 1, ds = 0, lambda = 0, 1/s := 0 throughout, so they
+                // contribute exact zeros / ones to every sum, product and maximum below -- see the start-point block)
+                for (int i = 0; i < NF; ++i) {
+                    const T a_ = sup[i] - alpha * aut[i], b_ = slo[i] + alpha * aut[i];
+                    const bool pos = a_ > 0 && b_ > 0;
+                    okp = okp && pos;
+                    if (sizeof(T) == 8) lpr *= pos ? a_ * b_ : (T)1;
+                    else lgt += log_pos(pos ? a_ * b_ : (T)1, kc);
+                }
                 if (sizeof(T) == 8) lgt = log_pos(lpr, kc);
                 okp = __all(okp);
                 const T slg = dpp_sum(lgt);
@@ -884,15 +886,14 @@ template <typename T, int N> struct FastSolver {
                 cs[C_LGS] = slg;  // = sum log(slack) of the new iterate: the next barrier value re-uses it
                 const T ad = cs[C_AD];
 #pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        const T su = sup[i], sl = slo[i];
-                        lu[i] += ad * ((mu - cub[lane + 64 * i] - lu[i] * su) * isu[i] + lu[i] * isu[i] * aut[i]);
-                        ll[i] += ad * ((mu - clb[lane + 64 * i] - ll[i] * sl) * isl[i] - ll[i] * isl[i] * aut[i]);
-                        sup[i] = su - alpha * aut[i];
-                        slo[i] = sl + alpha * aut[i];
-                        isu[i] = rcp_(sup[i]); isl[i] = rcp_(slo[i]);
-                    }
+                for (int i = 0; i < NF; ++i) {
+                    const T su = sup[i], sl = slo[i];
+                    lu[i] += ad * ((mu - cub[lane + 64 * i] - lu[i] * su) * isu[i] + lu[i] * isu[i] * aut[i]);
+                    ll[i] += ad * ((mu - clb[lane + 64 * i] - ll[i] * sl) * isl[i] - ll[i] * isl[i] * aut[i]);
+                    sup[i] = su - alpha * aut[i];
+                    slo[i] = sl + alpha * aut[i];
+                    isu[i] = fv[i] ? rcp_(sup[i]) : (T)0; isl[i] = fv[i] ? rcp_(slo[i]) : (T)0;
+                }
             }
             const bool restep = mode == RESTEP;
             if (!restep) {
@@ -922,11 +923,10 @@ template <typename T, int N> struct FastSolver {
                     for (int i = 0; i < NF; ++i) { lu[i] = mu * isu[i]; ll[i] = mu * isl[i]; }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < NF; ++i)
-                        if (fv[i]) {
-                            lu[i] = fmax(fmin(lu[i], kappa_sigma * mu * isu[i]), mu * isu[i] * ((T)1 / kappa_sigma));
-                            ll[i] = fmax(fmin(ll[i], kappa_sigma * mu * isl[i]), mu * isl[i] * ((T)1 / kappa_sigma));
-                        }
+                    for (int i = 0; i < NF; ++i) {
+                        lu[i] = fmax(fmin(lu[i], kappa_sigma * mu * isu[i]), mu * isu[i] * ((T)1 / kappa_sigma));
+                        ll[i] = fmax(fmin(ll[i], kappa_sigma * mu * isl[i]), mu * isl[i] * ((T)1 / kappa_sigma));
+                    }
                 }
                 if (iters >= max_iter) { mode = FINAL; Ut = U; continue; }  // status stays ITERATION_LIMIT
                 ++iters;
@@ -936,11 +936,10 @@ template <typename T, int N> struct FastSolver {
                 const T rd = sc * g + forms_applyT(w);
                 T lsum = 0, cm0 = 0, gap = 0;
 #pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        const T cu = sup[i] * lu[i], cl = slo[i] * ll[i];
-                        lsum += lu[i] + ll[i]; gap += cu + cl; cm0 = fmax(cm0, fmax(cu, cl));
-                    }
+                for (int i = 0; i < NF; ++i) {
+                    const T cu = sup[i] * lu[i], cl = slo[i] * ll[i];
+                    lsum += lu[i] + ll[i]; gap += cu + cl; cm0 = fmax(cm0, fmax(cu, cl));
+                }
                 const T rdm = dpp_max_nn(fabs(rd));
                 lsum = dpp_sum(lsum); cm0 = dpp_max_nn(cm0); gap = dpp_sum(gap);
                 constexpr T inv2nf = (T)1 / (T)(2 * nf);
@@ -985,7 +984,7 @@ template <typename T, int N> struct FastSolver {
             }
             // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
 #pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] * isu[i] + ll[i] * isl[i] : (T)0;
+            for (int i = 0; i < NF; ++i) w[i] = lu[i] * isu[i] + ll[i] * isl[i];
             stage_form_weights(w);
             STAMP(6);
             bool factored;
@@ -1039,22 +1038,20 @@ template <typename T, int N> struct FastSolver {
                 // step lengths to the boundary as reciprocals: 1/alpha = max(1, max_f(-ds/s)); for the affine step -dlam/lam = 1 + ds/s
                 T rpa = 1, rda = 1, mucur = 0, muaff = 0;
 #pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        const T qu = aut[i] * isu[i], ql = aut[i] * isl[i];  // -ds_u/s_u, ds_l/s_l
-                        rpa = fmax(rpa, fmax(qu, -ql));
-                        rda = fmax(rda, fmax((T)1 - qu, (T)1 + ql));
-                        mucur += sup[i] * lu[i] + slo[i] * ll[i];
-                    }
+                for (int i = 0; i < NF; ++i) {
+                    const T qu = aut[i] * isu[i], ql = aut[i] * isl[i];  // -ds_u/s_u, ds_l/s_l
+                    rpa = fmax(rpa, fmax(qu, -ql));
+                    rda = fmax(rda, fmax((T)1 - qu, (T)1 + ql));
+                    mucur += sup[i] * lu[i] + slo[i] * ll[i];
+                }
                 const T apa = rcp_(dpp_max_nn(rpa)), ada = rcp_(dpp_max_nn(rda));
 #pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
-                        const T dlu = -lu[i] - lu[i] * isu[i] * dsu, dll = -ll[i] - ll[i] * isl[i] * dsl;
-                        muaff += (su + apa * dsu) * (lu[i] + ada * dlu) + (sl + apa * dsl) * (ll[i] + ada * dll);
-                        cub[lane + 64 * i] = dsu * dlu; clb[lane + 64 * i] = dsl * dll;
-                    }
+                for (int i = 0; i < NF; ++i) {
+                    const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
+                    const T dlu = -lu[i] - lu[i] * isu[i] * dsu, dll = -ll[i] - ll[i] * isl[i] * dsl;
+                    muaff += (su + apa * dsu) * (lu[i] + ada * dlu) + (sl + apa * dsl) * (ll[i] + ada * dll);
+                    cub[lane + 64 * i] = dsu * dlu; clb[lane + 64 * i] = dsl * dll;
+                }
                 mucur = dpp_sum(mucur) * ((T)1 / (T)(2 * nf)); muaff = dpp_sum(muaff) * ((T)1 / (T)(2 * nf));
                 const T r3 = muaff * rcp_(mucur);
                 mu = fmax(cs[C_MUF], fmin((T)1, r3 * r3 * r3) * mucur);
@@ -1069,7 +1066,7 @@ template <typename T, int N> struct FastSolver {
             }
             // centering (+ corrector) part of the step: du = K^{-1}(-sc*g - A^T((mu - corr)/s_u - (mu - corr)/s_l))
 #pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - cub[lane + 64 * i]) * isu[i] - (mu - clb[lane + 64 * i]) * isl[i]) : (T)0;
+            for (int i = 0; i < NF; ++i) w[i] = -((mu - cub[lane + 64 * i]) * isu[i] - (mu - clb[lane + 64 * i]) * isl[i]);
             du = back_subst((lane < n ? Lc[offc_rt(lane) + n] : (T)0) + diag_solve(fwd_subst(forms_applyT(w))));
             STAMP(15);
             forms_apply(du, aut);
