@@ -48,7 +48,12 @@ template <typename T> DEV T scan_suffix(T x, int lane) {  // inclusive, lane 63 
     for (int d = 1; d < 64; d <<= 1) { T t = __shfl_down(x, d); if (lane + d < 64) x += t; }
     return x;
 }
-#define WSYNC() __syncthreads()
+// Every solver kernel runs ONE wave per workgroup: cross-lane exchange through LDS needs program order only (a wave's LDS
+// operations execute in order), so the "workgroup barrier" is a wave-level fence for the compiler -- __syncthreads() would add
+// s_waitcnt lgkmcnt(0) + s_barrier, a full drain of the LDS queue, at every exchange.
+#define WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define WSYNC() WFENCE()
 
 // phase stamps: diagnostic builds only (-DKMPC_STAMPS); the shipped library has none.  -DKMPC_TRACE (diagnostic too) turns the
 // stamp buffer into a per-iteration record of one problem: row `it` = 8 doubles (tools/trace_problem.py)

@@ -28,13 +28,6 @@
 //     20 KB of LDS per wave = exactly 8 waves per CU at N = 20).
 #include "kmpc_common.h"
 
-#define WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
-                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-// One wave per workgroup: cross-lane exchange through LDS needs program order only (a wave's LDS operations execute in order), so
-// the workgroup barrier of the generic kernel -- s_waitcnt lgkmcnt(0) + s_barrier, a full drain of the LDS queue -- becomes the
-// wave-level fence here.
-#undef WSYNC
-#define WSYNC() WFENCE()
 
 DEV void pin(double &x) { asm volatile("" : "+v"(x)); }
 DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
