@@ -162,7 +162,8 @@ template <typename T, int N> struct FastSolver {
     // read from there: the kernarg segment arrives as 16-SGPR tuples which the allocator spills and then reloads WHOLE at every use
     // of any member (~600 v_readlane per iteration before this table).
     enum { PT_DT = 0, PT_DTC, PT_RR, PT_DT2, PT_DTL, PT_LB, PT_TOL, PT_GAP_TOL, PT_TOL_X100, PT_TOL_X1000, PT_TOL_D100, PT_TOL_D10,
-           PT_STEER_MAX, PT_A_MAX, PT_STEER_DMAX, PT_A_DMAX, PT_W = 16, PT_V_MIN = 24, PT_V_MAX, PT_RELAX, PT_WARM_PUSH, PT_WARM_MU, PT_MU_INIT };
+           PT_STEER_MAX, PT_A_MAX, PT_STEER_DMAX, PT_A_DMAX, PT_W = 16, PT_V_MIN = 24, PT_V_MAX, PT_RELAX, PT_WARM_PUSH, PT_WARM_MU, PT_MU_INIT,
+           PT_INV2NF /* 1 / (2 nf): an fp64 literal in the loop would be hoisted into (and spilled from) a VGPR pair */ };
     const T *pt, *cwt;
 
     DEV FastSolver(const KP &p, unsigned char *smem) : P(p), lane(threadIdx.x)
@@ -192,7 +193,7 @@ template <typename T, int N> struct FastSolver {
             q[PT_W + 0] = (T)p.C2[0]; q[PT_W + 1] = (T)p.C2[1]; q[PT_W + 2] = (T)p.C2[2]; q[PT_W + 3] = (T)p.C2[3];
             q[PT_W + 4] = (T)p.C2[4]; q[PT_W + 5] = (T)p.C2[5]; q[PT_W + 6] = (T)p.C2[6]; q[PT_W + 7] = (T)p.C2[7];
             q[PT_V_MIN] = (T)p.v_min; q[PT_V_MAX] = (T)p.v_max; q[PT_RELAX] = (T)p.relax; q[PT_WARM_PUSH] = (T)p.warm_push;
-            q[PT_WARM_MU] = (T)p.warm_mu; q[PT_MU_INIT] = (T)p.mu_init;
+            q[PT_WARM_MU] = (T)p.warm_mu; q[PT_MU_INIT] = (T)p.mu_init; q[PT_INV2NF] = (T)(1.0 / (2 * nf));
         }
     }
 
@@ -460,7 +461,9 @@ template <typename T, int N> struct FastSolver {
     // when the exact Hessian is wanted, and a fallback inside an iteration clears them (drop_second_order).
     DEV void drop_second_order()
     {
-        if (lane <= N) { T *q = lin + LIN_STRIDE * lane; q[8] = q[9] = q[10] = q[11] = q[12] = (T)0; }
+        T z = (T)0;
+        pin(z);  // materialised here: hoisted out of the iteration loop this zero would occupy (and spill) a VGPR pair for the whole solve
+        if (lane <= N) { T *q = lin + LIN_STRIDE * lane; q[8] = z; q[9] = z; q[10] = z; q[11] = z; q[12] = z; }
         WSYNC();
     }
     DEV void condense(T sc, acc_t (&acc)[NTT])
@@ -935,7 +938,7 @@ template <typename T, int N> struct FastSolver {
                 }
                 const T rdm = dpp_max_nn(fabs(rd));
                 lsum = dpp_sum(lsum); cm0 = dpp_max_nn(cm0); gap = dpp_sum(gap);
-                constexpr T inv2nf = (T)1 / (T)(2 * nf);
+                const T inv2nf = pt[PT_INV2NF];
                 const T isd = s_max * rcp_(fmax(s_max, lsum * inv2nf));  // 1 / s_d
                 const T err0 = fmax(rdm, cm0) * isd;
                 const T tol = pt[PT_TOL];
@@ -1045,7 +1048,7 @@ template <typename T, int N> struct FastSolver {
                     muaff += (su + apa * dsu) * (lu[i] + ada * dlu) + (sl + apa * dsl) * (ll[i] + ada * dll);
                     cub[lane + 64 * i] = dsu * dlu; clb[lane + 64 * i] = dsl * dll;
                 }
-                mucur = dpp_sum(mucur) * ((T)1 / (T)(2 * nf)); muaff = dpp_sum(muaff) * ((T)1 / (T)(2 * nf));
+                mucur = dpp_sum(mucur) * pt[PT_INV2NF]; muaff = dpp_sum(muaff) * pt[PT_INV2NF];
                 const T r3 = muaff * rcp_(mucur);
                 mu = fmax(cs[C_MUF], fmin((T)1, r3 * r3 * r3) * mucur);
                 mu = fmax(mu, fmin(mucur, cs[C_RDS] * (T)KMPC_IKRD));  // no barrier target far below the dual infeasibility
