@@ -732,7 +732,7 @@ template <typename T, int N> struct FastSolver {
         }
         const T vref = len / ((T)(N - 1) * dt);
         const T sb = fmin(fmax(pt[PT_LB] * kap, (T)-0.9), (T)0.9);
-        const T dff = fmin(fmax(atan(tan(asin(sb)) / rr), -frac * steer_max), frac * steer_max);
+        const T dff = fmin(fmax(atan(sb * rsqrt_((T)1 - sb * sb) / rr)  /* tan(asin(sb)) = sb / sqrt(1 - sb^2), |sb| <= 0.9 */, -frac * steer_max), frac * steer_max);
         const T aff = fmin(fmax(vref - v0, -frac * a_max), frac * a_max);
         T u0[2];
         // Q5: v[1] = v0 is itself bounded in the reference model -> any v0 outside the (relaxed) speed bounds is infeasible

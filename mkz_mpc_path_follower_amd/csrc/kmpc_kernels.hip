@@ -795,7 +795,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         if (MODEL == 1) kap = ((kp0 * x0 + kp1) * x0 + kp2) * x0 + kp3;  // Frenet: curvature of the polynomial at s0
         const T vref = MODEL == 1 ? vt : len / ((T)(N - 1) * dt);
         const T sb = fmin(fmax((T)P.L_b * kap, (T)-0.9), (T)0.9);
-        const T dff = fmin(fmax(atan(tan(asin(sb)) / rr), -frac * (T)P.steer_max), frac * (T)P.steer_max);
+        const T dff = fmin(fmax(atan(sb / sqrt((T)1 - sb * sb) / rr)  /* tan(asin(sb)) = sb / sqrt(1 - sb^2), |sb| <= 0.9 */, -frac * (T)P.steer_max), frac * (T)P.steer_max);
         const T aff = fmin(fmax(vref - v0, -frac * (T)P.a_max), frac * (T)P.a_max);
         T u0[2];
         // Q5: v[1] = v0 is itself bounded in the reference model -> any v0 outside the (relaxed) speed bounds is infeasible
