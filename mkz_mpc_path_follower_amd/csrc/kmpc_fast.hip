@@ -799,6 +799,7 @@ template <typename T, int N> struct FastSolver {
         const bool pc = P.mu_strategy == 1;
         bool corr_active = false, first_attempt = true, tiny_stop = false;
         int n_tiny = 0, n_flat = 0;
+        bool final_reuse = false;  // FINAL reached with St / Jt already holding the evaluation of the returned iterate
 #pragma unroll
         for (int i = 0; i < NF; ++i) cub[lane + 64 * i] = clb[lane + 64 * i] = (T)0;
         int mode = FIRST;
@@ -837,9 +838,10 @@ template <typename T, int N> struct FastSolver {
             asm volatile("" : "+v"(lane));
             if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && cs[C_ERR] <= pt[PT_TOL])) {
                 // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
-                Ut = ubest[lane]; U = Ut; status = 0;
+                Ut = ubest[lane]; U = Ut; status = 0; final_reuse = false;
             }
-            if (mode != REFACTOR && mode != RESTEP) Jt = eval(Ut, St);  // refactor / restep passes re-use the linearisation of U
+            // refactor / restep passes re-use the linearisation of U; a stop decided on the iterate that was just evaluated re-uses that too
+            if (mode != REFACTOR && mode != RESTEP && !final_reuse) Jt = eval(Ut, St);
             STAMP(9);
             if (mode == FINAL) break;
             if (mode == TRIAL) {
@@ -876,7 +878,7 @@ template <typename T, int N> struct FastSolver {
                 {
                     const T stepn = dpp_max_nn(fabs(alpha * du)), umax = fmax((T)1, dpp_max_nn(fabs(U)));
                     n_tiny = stepn <= (T)10 * Real<T>::eps() * umax ? n_tiny + 1 : 0;
-                    if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= pt[PT_TOL_X1000] ? 0 : 3; tiny_stop = true; mode = FINAL; continue; }
+                    if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= pt[PT_TOL_X1000] ? 0 : 3; tiny_stop = true; mode = FINAL; final_reuse = true; continue; }
                 }
                 // accepted: dual step from the pre-step slacks, then the slacks advance with the step
                 cs[C_LGS] = slg;  // = sum log(slack) of the new iterate: the next barrier value re-uses it
@@ -924,7 +926,7 @@ template <typename T, int N> struct FastSolver {
                         ll[i] = fmax(fmin(ll[i], kappa_sigma * mu * isl[i]), mu * isl[i] * ((T)1 / kappa_sigma));
                     }
                 }
-                if (iters >= max_iter) { mode = FINAL; Ut = U; continue; }  // status stays ITERATION_LIMIT
+                if (iters >= max_iter) { mode = FINAL; Ut = U; final_reuse = true; continue; }  // status stays ITERATION_LIMIT
                 ++iters;
                 // optimality error (Ipopt's scaled test + unscaled duality-gap bound)
 #pragma unroll
@@ -958,7 +960,7 @@ template <typename T, int N> struct FastSolver {
                 n_flat = fabs(Jt - cs[C_JP]) <= (T)20 * Real<T>::eps() * fmax((T)1, fabs(Jt)) ? n_flat + 1 : 0;
                 cs[C_JP] = Jt;
                 if (n_flat >= 12 && err0 <= pt[PT_TOL_X1000]) done = true;
-                if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
+                if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; final_reuse = true; continue; }
                 const T mu_min = fmax(pt[PT_TOL_D100], fmin(pt[PT_TOL_D10], (T)0.1 * gap_lim * sc * inv2nf));
                 cs[C_MUF] = mu_min;
 #pragma nounroll
@@ -1008,7 +1010,7 @@ template <typename T, int N> struct FastSolver {
                 // Indefinite exact Hessian: strategy 0 -> Gauss-Newton for this and the next 2 iterations; 1 -> Ipopt's inertia
                 // correction K + delta_w*I, delta_w = 1e-2*max|sc*H_jj| (x10) the first time, last/3 (x8) afterwards;
                 // 2 -> 0 until the second failure, 1 from then on (Gauss-Newton leaves a saddle only slowly)
-                if (++attempt >= 40) { status = 3; mode = FINAL; Ut = U; continue; }
+                if (++attempt >= 40) { status = 3; mode = FINAL; Ut = U; final_reuse = true; continue; }
                 if (use_exact && indef == 1) {
                     const T hmax = cs[C_HMAX], dw_last = cs[C_DWL];
                     if (reg == (T)0) reg = dw_last > (T)0 ? fmax((T)1e-10 * hmax, dw_last / (T)3) : (T)1e-2 * hmax;
