@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 MFMA (v_mfma_f64_16x16x4) spec rate, SURVEY.md section 7.2
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
 
 
 def algorithmic_bytes_per_solve(N, es):
@@ -41,13 +42,67 @@ def algorithmic_flops_per_iteration(N):
 
 
 def measured_traffic_bytes():
-    """HBM bytes per 4096-problem dispatch from the committed PMC passes (profiles/r1_pmc_traffic.json), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            j = json.load(f)
-            return float(j["runs"][j["current"]]["hbm_bytes_per_dispatch"])
-    except Exception:
-        return None
+    """(HBM bytes per 4096-problem dispatch, source) from the committed PMC passes (profiles/r*_pmc_traffic.json), or (None, None).
+    PMC counters need their own rocprofv3 passes (tools/pmc_quick.sh); this run does not collect them -- the figure is the
+    committed one of the same kernel build, and the JSON line says so."""
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                j = json.load(f)
+                return float(j["runs"][j["current"]]["hbm_bytes_per_dispatch"]), "profiles/%s (%s): committed rocprofv3 --pmc passes, not measured in this run" % (name, j["current"])
+        except Exception:
+            continue
+    return None, None
+
+
+def time_launches(solver, din, steps, warmup):
+    """mean HIP-event duration (ms) of `steps` launches over resident inputs, after `warmup` untimed ones; -> (ms, last outputs)"""
+    out = None
+    for _ in range(warmup):
+        out = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=out)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    for e0, e1 in ev:
+        e0.record()
+        out = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=out)
+        e1.record()
+    torch.cuda.synchronize()
+    return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])), out
+
+
+def multi_seed(solver, N, B, tdt, dev, seeds=8, steps=10, warmup=2):
+    """The launch time of a few thousand problems is set by its slowest problems, so it depends on the draw: the same workload
+    on `seeds` OTHER seeded batches (the headline batch is not among them)."""
+    from mkz_mpc_path_follower_amd.synthetic import make_batch
+    rates, its = [], []
+    for s in range(seeds):
+        d = make_batch(B, N, cfg_id=2, seed=20180620 + 7919 * (s + 1))
+        din = {k: torch.as_tensor(d[k], dtype=tdt, device=dev) for k in ("z0", "ref", "v_target", "u_prev")}
+        ms, out = time_launches(solver, din, steps, warmup)
+        rates.append(B / (ms * 1e-3)); its.append(out["iters"].float().mean().item())
+        assert int((out["status"] == 0).sum().item()) == B
+    return {"seeds": seeds, "launches_per_seed": steps, "mean": float(np.mean(rates)), "min": float(np.min(rates)), "max": float(np.max(rates)),
+            "unit": "solves/s", "mean_iterations": float(np.mean(its)), "all_optimal": True}
+
+
+def other_config(N, B, dtype, cfg_id, dev, local, steps=5, warmup=2):
+    """untimed-headline extra key: one of the other BASELINE configs on this GPU (kernel time by HIP events over resident inputs)"""
+    from mkz_mpc_path_follower_amd import BatchMPC
+    from mkz_mpc_path_follower_amd.synthetic import make_batch
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    d = make_batch(B, N, cfg_id=cfg_id)
+    din = {k: torch.as_tensor(d[k], dtype=tdt, device=dev) for k in ("z0", "ref", "v_target", "u_prev")}
+    solver = BatchMPC(N=N, dtype=tdt, device=local)
+    ms, out = time_launches(solver, din, steps, warmup)
+    iters = out["iters"].float().mean().item()
+    peak = FP64_PEAK_TFLOPS if dtype == "f64" else FP32_PEAK_TFLOPS
+    tf = algorithmic_flops_per_iteration(N) * iters * B / (ms * 1e-3) / 1e12
+    es = 8 if dtype == "f64" else 4
+    return {"workload": "batch=%d, N=%d, %s, 1 GPU, seeded synthetic (cfg_id %d)" % (B, N, dtype, cfg_id), "solves_per_s": B / (ms * 1e-3),
+            "kernel_ms": ms, "launches": steps, "mean_iterations": iters, "max_iterations": int(out["iters"].max().item()),
+            "optimal_fraction": float((out["status"] == 0).float().mean().item()),
+            "achieved_tflops": tf, "peak_tflops": peak, "frac_of_peak": tf / peak,
+            "hbm_gbs_algorithmic": algorithmic_bytes_per_solve(N, es) * B / (ms * 1e-3) / 1e9}
 
 
 def closed_loop_latency(device, steps=150):
@@ -104,6 +159,13 @@ def parity_sample(N, d, out, ro, tol=1e-6):
     return info
 
 
+def kernel_name(N, dtype):
+    t = "double" if dtype == "f64" else "float"
+    if N in (8, 12, 16, 20, 24, 28):
+        return "kmpc_solve_fast_kernel<%s,%d>" % (t, N)
+    return "kmpc_solve_kernel<%s>" % t
+
+
 def host_cores():
     """threads worth starting: the affinity mask, capped by the cgroup CPU quota when there is one (a 1-GPU box exposes 256 logical
     CPUs but grants a share of them)"""
@@ -154,13 +216,25 @@ def main():
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="skip the multi-seed and other-config extra keys")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank control flow on a one-GPU box)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run child) BEFORE any
+        # GPU call in this process -- a process that has touched the GPU must never be replaced or forked from
+        from mkz_mpc_path_follower_amd.dist import spawn_ranks
+        if a.backend == "nccl" and torch.cuda.device_count() < a.gpus:  # device_count() does not initialise the GPU on this image
+            sys.exit("bench.py: --gpus %d but %d GPU(s) visible (use --backend gloo to rehearse the multi-rank control flow on fewer)"
+                     % (a.gpus, torch.cuda.device_count()))
+        sys.exit(spawn_ranks(os.path.abspath(__file__), a.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)" % (a.gpus, world, a.gpus))
     if a.backend == "gloo":
         local = local % torch.cuda.device_count()  # rehearsal: the ranks share the box's GPU(s)
     torch.cuda.set_device(local)
@@ -171,6 +245,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == a.gpus
 
     from mkz_mpc_path_follower_amd import BatchMPC
     from mkz_mpc_path_follower_amd.dist import SolutionGather
@@ -230,7 +305,7 @@ def main():
         byts = algorithmic_bytes_per_solve(N, es) * Bl
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
         ach_gbs = byts / (kern_ms * 1e-3) / 1e9
-        traffic = measured_traffic_bytes() if (world == 1 and Bl == 4096 and N == 20 and a.dtype == "f64") else None
+        traffic, traffic_src = measured_traffic_bytes() if (world == 1 and Bl == 4096 and N == 20 and a.dtype == "f64") else (None, None)
         res = {
             "metric": "MPC solves/sec (batch, N=20 bicycle)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
@@ -239,10 +314,13 @@ def main():
                                    % (Bl, N, a.dtype),
                        "batch_per_gpu": Bl, "global_batch": B, "horizon": N, "parallelism": "shard%d" % world,
                        "mean_iterations": iters, "optimal_fraction": n_opt / Bl},
-            # the path is compute/latency-bound: fp64 VALU+MFMA roofline is the binding one
-            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "kmpc_solve_fast_kernel<double,20>" if (N == 20 and a.dtype == "f64") else "kmpc_solve_kernel", "kernel_ms": kern_ms,
+            # the path is compute/latency-bound.  The SQ counters (profiles/r*_sq_counters.json) say the kernel is bound by
+            # fp64 VALU ISSUE while the chip is full and by single-wave latency in the tail, not by the matrix cores; the denominator is the
+            # fp64 vector = fp64 MFMA peak (78.6 TFLOP/s), the numerator counts ALGORITHMIC flops only (SURVEY.md 8(d) formula)
+            "roofline": {"bound": "valu", "bound_note": "fp64 VALU issue / wave latency (MFMA pipes ~11 % busy); priced against the fp64 vector = MFMA peak",
+                         "achieved": ach_tf, "peak": (FP64_PEAK_TFLOPS if a.dtype == "f64" else FP32_PEAK_TFLOPS), "unit": "TFLOP/s",
+                         "frac": ach_tf / (FP64_PEAK_TFLOPS if a.dtype == "f64" else FP32_PEAK_TFLOPS), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name(N, a.dtype), "kernel_ms": kern_ms,
                          "flops_per_solve": algorithmic_flops_per_iteration(N) * iters},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": byts,
@@ -261,6 +339,17 @@ def main():
                 lat.append(time.perf_counter() - t)
             res["p50_latency_us_B1"] = float(np.percentile(lat[10:], 50) * 1e6)
             res["closed_loop_N8"] = closed_loop_latency(local)
+            if Bl == 4096 and N == 20 and a.dtype == "f64" and not a.quick:
+                # the headline batch is one draw; the same workload over 8 other seeded batches (launch time = slowest problem of the draw)
+                res["multi_seed"] = multi_seed(solver, N, Bl, tdt, dev)
+                # the other single-GPU BASELINE configs, untimed-headline extra keys: configs[2] (fp32, B = 262144) and configs[4] (N = 50)
+                res["config3_fp32_B262144"] = other_config(20, 262144, "f32", 3, dev, local, steps=5, warmup=2)
+                res["config5_N50_B4096"] = other_config(50, 4096, "f64", 5, dev, local, steps=5, warmup=2)
+                # the shard one GPU of configs[3] (2 097 152 problems over 8 GPUs) gets, fp64
+                res["config4_shard_fp64_B262144"] = other_config(20, 262144, "f64", 4, dev, local, steps=3, warmup=1)
+            # the reference's own Julia/Ipopt path is timed only if it is already installed (never fetched)
+            import shutil
+            res["reference_julia_ipopt_baseline"] = ("julia found at %s: not run (the reference's files do not travel)" % shutil.which("julia")) if shutil.which("julia") else "unavailable (no julia on this host)"
             if not a.no_cpu_baseline:
                 cb, ro = cpu_baseline(N, d)
                 res["cpu_baseline"] = cb

@@ -17,6 +17,8 @@ template <typename T> hipError_t kmpc_launch_condense(const KP &, const KDbg<T> 
 template <typename T> hipError_t kmpc_launch_probe(const T *, const T *, T *, hipStream_t);
 template <typename T> bool kmpc_fast_available(int N);
 template <typename T> hipError_t kmpc_launch_solve_fast(const KP &, const KIO<T> &, hipStream_t);
+template <typename T> bool kmpc_wide_available(int N);
+template <typename T> hipError_t kmpc_launch_solve_wide(const KP &, const KIO<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_solve_frenet(const KP &, const KIO<T> &, hipStream_t);
 hipError_t kmpc_launch_sim(int, double *, const double *, int, hipStream_t);
 template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, const T *, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
@@ -218,7 +220,8 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
         h->sched_parity ^= 1;
         io.perm = h->perm;
     }
-    if (h->cfg.kernel_variant == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));
+    if (h->cfg.kernel_variant == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));        // one wave per problem
+    else if (h->cfg.kernel_variant == 0 && kmpc_wide_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_wide<T>(P, io, st));  // four waves per problem
     else HIPCHK(h, kmpc_launch_solve<T>(P, io, st));
     return KMPC_OK;
 }

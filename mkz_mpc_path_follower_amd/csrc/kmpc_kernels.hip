@@ -1257,12 +1257,25 @@ __global__ __launch_bounds__(64) void kmpc_mfma_probe_kernel(const T *a, const T
 }
 
 // ---- launchers (called from kmpc_api.hip) ------------------------------------------------------
+// The dynamic-LDS limit of a kernel is a property of the (function, device) pair: it is raised once, the first time a launch
+// needs more than what was set before (horizons differ in their LDS need), not on every launch.
+template <typename K> static hipError_t ensure_dynamic_lds(K kernel, size_t lds, size_t (&set_for_device)[64])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (lds <= set_for_device[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) set_for_device[dev] = lds;
+    return e;
+}
 template <typename T, int NT>
 static hipError_t launch_solve_nt(const KP &P, const KIO<T> &io, hipStream_t st)
 {
     const size_t lds = kmpc_lds_bytes<T>(P.N, NT);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kmpc_solve_kernel<T, NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t lds_set[64] = {0};
+    hipError_t e = ensure_dynamic_lds(&kmpc_solve_kernel<T, NT>, lds, lds_set);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((kmpc_solve_kernel<T, NT>), dim3(P.B), dim3(64), lds, st, P, io);
     return hipGetLastError();
@@ -1271,8 +1284,8 @@ template <typename T, int NT>
 static hipError_t launch_solve_frenet_nt(const KP &P, const KIO<T> &io, hipStream_t st)
 {
     const size_t lds = kmpc_lds_bytes<T>(P.N, NT);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kmpc_solve_frenet_kernel<T, NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t lds_set[64] = {0};
+    hipError_t e = ensure_dynamic_lds(&kmpc_solve_frenet_kernel<T, NT>, lds, lds_set);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((kmpc_solve_frenet_kernel<T, NT>), dim3(P.B), dim3(64), lds, st, P, io);
     return hipGetLastError();
@@ -1281,8 +1294,8 @@ template <typename T, int NT>
 static hipError_t launch_condense_nt(const KP &P, const KDbg<T> &io, hipStream_t st)
 {
     const size_t lds = kmpc_lds_bytes<T>(P.N, NT);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kmpc_condense_kernel<T, NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t lds_set[64] = {0};
+    hipError_t e = ensure_dynamic_lds(&kmpc_condense_kernel<T, NT>, lds, lds_set);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((kmpc_condense_kernel<T, NT>), dim3(P.B), dim3(64), lds, st, P, io);
     return hipGetLastError();

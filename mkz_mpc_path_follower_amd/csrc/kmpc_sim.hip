@@ -27,8 +27,10 @@ __global__ __launch_bounds__(256) void kmpc_sim_kernel(int B, double *__restrict
             alpha_r = -atan2(vy - lf * wz, vx);                     // :77 (lf where lr is expected -- as in the reference)
         }
         const double Fyf = C_alpha_f * alpha_f, Fyr = C_alpha_r * alpha_r;  // :80-81
-        const double sd = sin(df), cd = cos(df), sp = sin(psi), cp = cos(psi);
-        const double vx_n = fmax(0.0, vx + deltaT * (acc - 1 / m * Fyf * sd + wz * vy));   // :84
+        const double cd = cos(df), sp = sin(psi), cp = cos(psi);
+        // :84 reads `acc - 1/m*Fyf*np.sin(self.df) + self.wz*self.vy` with m = 1840 an int: the reference is Python 2 (print statements,
+        // no `from __future__ import division`), so 1/m is INTEGER division = 0 and the lateral-force drag term vanishes (:88 uses 1.0/m)
+        const double vx_n = fmax(0.0, vx + deltaT * (acc + wz * vy));
         double vy_n = 0.0, wz_n = 0.0;
         if (vx_n > 1e-6) {                                          // :87
             vy_n = vy + deltaT * (1.0 / m * (Fyf * cd + Fyr) - wz * vx);               // :88

@@ -59,7 +59,10 @@ __global__ __launch_bounds__(64) void kmpc_waypoints_kernel(WP w)
     }
     const double dmin = dpp_min(best);
     const double cand = (best == dmin) ? (double)bi : 1e18;
-    const int closest = (int)dpp_min(cand);
+    int closest = (int)dpp_min(cand);
+    // a non-finite pose (NaN or +-inf from the GPS / plant) makes every distance NaN or +inf: no lane records an index.  np.argmin
+    // returns 0 then (first NaN / first of the equal minima), and so does this -- never an index outside the path arrays
+    closest = (unsigned)closest < (unsigned)w.M ? closest : 0;
     // ---- look-ahead grid ---------------------------------------------------------------------------
     const int k = lane;
     const bool act = k <= w.H;

@@ -66,3 +66,23 @@ class SolutionGather:
             w.wait()
             self.work[slot] = None
         return self.out[slot]
+
+
+def spawn_ranks(script, nproc, args, master_port=None, extra_env=None, timeout=None):
+    """Start `nproc` ranks of `script` on this node (one process per GPU) as a `torch.distributed.run` CHILD process and return its
+    exit code.  Must be called before the calling process touches the GPU (the caller stays a plain launcher: it neither forks
+    GPU state nor replaces itself).  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    if master_port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            master_port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL / cross-process tensors)
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)),
+           "--master-addr", "127.0.0.1", "--master-port", str(master_port), script] + list(args)
+    return subprocess.call(cmd, env=env, timeout=timeout)

@@ -61,76 +61,56 @@ class BatchMPC:
             raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
         return t
 
-    def solve(self, z0, ref, v_target, u_prev, warm_U=None, warm=False, want_U=False, want_X=False, out=None):
-        """z0[B,4], ref[B,N+1,3], v_target[B], u_prev[B,2] (acc, steer) -> dict of device tensors.
+    def _outputs(self, out, B, want_U, want_X):
+        """output tensors of one call: those in `out` are reused when they fit (B, dtype, device), anything else is (re)allocated --
+        a buffer left over from a call with another batch size or element type must never reach the kernel as a raw pointer"""
+        N = self.N
+        o = out if out is not None else {}
+        spec = {"u0": ((B, 2), self.dtype), "status": ((B,), torch.int32), "cost": ((B,), self.dtype), "viol": ((B,), self.dtype),
+                "iters": ((B,), torch.int32)}
+        if want_U:
+            spec["U"] = ((B, N, 2), self.dtype)
+        if want_X:
+            spec["X"] = ((B, N + 1, 4), self.dtype)
+        for k, (shape, dt) in spec.items():
+            t = o.get(k)
+            if not (isinstance(t, torch.Tensor) and tuple(t.shape) == shape and t.dtype == dt and t.device == self.device and t.is_contiguous()):
+                o[k] = torch.empty(shape, dtype=dt, device=self.device)
+        return o
 
-        Asynchronous on torch's current stream.  `out` may carry preallocated output tensors from a
-        previous call (reused, no allocation in the timed path).
-        """
+    def _solve(self, entry, z0, second, second_shape, v_target, u_prev, warm_U, warm, want_U, want_X, out):
         N = self.N
         z0 = self._dev(z0, (len(z0), 4))
         B = z0.shape[0]
-        ref = self._dev(ref, (B, N + 1, 3))
+        second = self._dev(second, (B,) + second_shape)
         v_target = self._dev(v_target, (B,))
         u_prev = self._dev(u_prev, (B, 2))
         if warm_U is not None:
             warm_U = self._dev(warm_U, (B, N, 2))
-        o = out if out is not None else {}
-        kw = dict(dtype=self.dtype, device=self.device)
-        if "u0" not in o:
-            o["u0"] = torch.empty((B, 2), **kw)
-            o["status"] = torch.empty((B,), dtype=torch.int32, device=self.device)
-            o["cost"] = torch.empty((B,), **kw)
-            o["viol"] = torch.empty((B,), **kw)
-            o["iters"] = torch.empty((B,), dtype=torch.int32, device=self.device)
-        if want_U and "U" not in o:
-            o["U"] = torch.empty((B, N, 2), **kw)
-        if want_X and "X" not in o:
-            o["X"] = torch.empty((B, N + 1, 4), **kw)
+        o = self._outputs(out, B, want_U, want_X)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = self.lib.kmpc_solve_batch(self.h, B, _ptr(z0), _ptr(ref), _ptr(v_target), _ptr(u_prev),
-                                       _ptr(warm_U), 1 if (warm and warm_U is not None) else 0,
-                                       _ptr(o["u0"]), _ptr(o["status"]), _ptr(o["cost"]), _ptr(o["viol"]),
-                                       _ptr(o["iters"]), _ptr(o.get("U") if want_U else None),
-                                       _ptr(o.get("X") if want_X else None), stream)
+        rc = entry(self.h, B, _ptr(z0), _ptr(second), _ptr(v_target), _ptr(u_prev),
+                   _ptr(warm_U), 1 if (warm and warm_U is not None) else 0,
+                   _ptr(o["u0"]), _ptr(o["status"]), _ptr(o["cost"]), _ptr(o["viol"]),
+                   _ptr(o["iters"]), _ptr(o["U"] if want_U else None),
+                   _ptr(o["X"] if want_X else None), stream)
         _lib.check(rc, self.h)
         if warm_U is not None:
             o["warm_U"] = warm_U
         return o
+
+    def solve(self, z0, ref, v_target, u_prev, warm_U=None, warm=False, want_U=False, want_X=False, out=None):
+        """z0[B,4], ref[B,N+1,3], v_target[B], u_prev[B,2] (acc, steer) -> dict of device tensors.
+
+        Asynchronous on torch's current stream.  `out` may carry the output dict of a previous call: its tensors are
+        reused when batch size, dtype and device match (no allocation in the timed path), otherwise replaced.
+        """
+        return self._solve(self.lib.kmpc_solve_batch, z0, ref, (self.N + 1, 3), v_target, u_prev, warm_U, warm, want_U, want_X, out)
 
     def solve_frenet(self, z0, k_poly, v_target, u_prev, warm_U=None, warm=False, want_U=False, want_X=False, out=None):
         """Frenet-frame variant (handle created with model=1): z0[B,4] = (s, e_y, e_psi, v), k_poly[B,4] curvature polynomial,
         highest degree first; X[B,N+1,4] = (s, e_y, e_psi, v).  Otherwise as solve()."""
-        N = self.N
-        z0 = self._dev(z0, (len(z0), 4))
-        B = z0.shape[0]
-        k_poly = self._dev(k_poly, (B, 4))
-        v_target = self._dev(v_target, (B,))
-        u_prev = self._dev(u_prev, (B, 2))
-        if warm_U is not None:
-            warm_U = self._dev(warm_U, (B, N, 2))
-        o = out if out is not None else {}
-        kw = dict(dtype=self.dtype, device=self.device)
-        if "u0" not in o:
-            o["u0"] = torch.empty((B, 2), **kw)
-            o["status"] = torch.empty((B,), dtype=torch.int32, device=self.device)
-            o["cost"] = torch.empty((B,), **kw)
-            o["viol"] = torch.empty((B,), **kw)
-            o["iters"] = torch.empty((B,), dtype=torch.int32, device=self.device)
-        if want_U and "U" not in o:
-            o["U"] = torch.empty((B, N, 2), **kw)
-        if want_X and "X" not in o:
-            o["X"] = torch.empty((B, N + 1, 4), **kw)
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = self.lib.kmpc_solve_batch_frenet(self.h, B, _ptr(z0), _ptr(k_poly), _ptr(v_target), _ptr(u_prev),
-                                              _ptr(warm_U), 1 if (warm and warm_U is not None) else 0,
-                                              _ptr(o["u0"]), _ptr(o["status"]), _ptr(o["cost"]), _ptr(o["viol"]),
-                                              _ptr(o["iters"]), _ptr(o.get("U") if want_U else None),
-                                              _ptr(o.get("X") if want_X else None), stream)
-        _lib.check(rc, self.h)
-        if warm_U is not None:
-            o["warm_U"] = warm_U
-        return o
+        return self._solve(self.lib.kmpc_solve_batch_frenet, z0, k_poly, (4,), v_target, u_prev, warm_U, warm, want_U, want_X, out)
 
     # ---- diagnostics for tests ------------------------------------------------------------------
     def debug_condense(self, z0, ref, v_target, U, hessian=1):

@@ -36,7 +36,8 @@ def update_vehicle_model(state, cmd, n_updates=1, disc_steps=DISC_STEPS):
         alpha_r = np.where(moving, -np.arctan2(vy - LF * wz, vx), 0.0)              # :77 (lf, as in the reference)
         Fyf = C_ALPHA_F * alpha_f                                                   # :80
         Fyr = C_ALPHA_R * alpha_r                                                   # :81
-        vx_n = np.maximum(0.0, vx + deltaT * (acc - 1 / MASS * Fyf * np.sin(df) + wz * vy))  # :84
+        # :84 `acc - 1/m*Fyf*np.sin(self.df) + ...` with m = 1840 (int) under Python 2: 1/m is integer division = 0, the term vanishes
+        vx_n = np.maximum(0.0, vx + deltaT * (acc - (1 // int(MASS)) * Fyf * np.sin(df) + wz * vy))  # :84
         fwd = vx_n > 1e-6                                                           # :87
         vy_n = np.where(fwd, vy + deltaT * (1.0 / MASS * (Fyf * np.cos(df) + Fyr) - wz * vx), 0.0)      # :88,91
         wz_n = np.where(fwd, wz + deltaT * (1.0 / IZ * (LF * Fyf * np.cos(df) - LR * Fyr)), 0.0)        # :89,92

@@ -1,0 +1,108 @@
+"""Independent certification of solver outputs (test helper; uses oracle/ -- test infrastructure).
+
+A returned input sequence U is certified WITHOUT trusting anything the solver reports.  The gradient of the state-eliminated
+objective comes from oracle/kmpc_nlp.c (costate sweep), the inequality rows from kmpc_ineq().  A certificate is a multiplier
+vector lam >= 0; (U, lam) goes through oracle/kmpc_nlp.c::kmpc_certify, which returns
+
+    stationarity     || grad J(U) + A^T lam ||_inf
+    violation        max_i (A U - b)_i            (UNRELAXED bounds of MKZMPCPathFollower.jl:65-86)
+    complementarity  max_i lam_i * slack_i
+    lam_min
+
+Candidate certificates: for each activity threshold t in 1e-6 ... 1, inf the non-negative least-squares multipliers on the rows
+whose slack is below t,  lam = argmin_{lam >= 0} ||grad J + A_act^T lam||_2  (zero elsewhere) -- and the same with the remaining
+rows filled with mu/slack_i (mu = median complementarity product of the active rows: what a point on the central path carries).
+An interior-point solution with complementarity ~1e-8 has no sharp active set (multipliers decay geometrically along chains
+of rate limits down to ~1e-6 at slacks ~1e-2), so the threshold trades stationarity against complementarity; the certificate
+reported is the candidate with the smallest max(stationarity, complementarity).
+
+Scaling.  Ipopt tests optimality on a SCALED problem (Waechter & Biegler 2006, eq. 5-6; option nlp_scaling_max_gradient = 100): the
+objective is multiplied by sc = min(1, 100 / |grad f(x_start)|_inf), fixed at the starting point, and the residuals are divided by
+s_d = max(100, |lam|_1 / m) / 100.  Two scalings are reported, both computed from the problem and U alone:
+  scaled_*      STRICT: sc from the gradient at the returned point, 1 / max(1, |grad J(U)|_inf / 100) -- at a solution the gradient is
+                what the active multipliers balance, typically 100-1000x smaller than at any starting point, so this is 1-3 decades
+                harsher than the test any Ipopt run applies;
+  ref_scaled_*  REFERENCE: sc from the gradient at the reference's own starting point, all inputs zero (`start=0.0`,
+                MKZMPCPathFollower.jl:65-72; Q9), 1 / max(1, |grad J(0)|_inf / 100) -- the scale on which the reference's
+                `tol = 1e-8` is stated.
+"""
+import numpy as np
+from scipy.optimize import nnls
+
+THRESHOLDS = (1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, np.inf)
+WIDE_FROM, WIDE_IF_ABOVE = 1.0, 2e-7   # thresholds >= 1 (NNLS over most rows: tens of ms at N = 50) only while the best certificate is worse than this
+
+
+def _nnls(M, rhs):
+    return nnls(M, rhs, maxiter=50 * M.shape[1] + 200)[0]
+
+
+def certify_one(O, p, z0, ref, v_target, u_prev, U, relax=1e-8):
+    q = O.problem(p, z0, ref, v_target, u_prev)
+    U = np.asarray(U, dtype=np.float64).reshape(-1)
+    A, b = O.ineq(p, q, relax=relax)
+    g = O.grad(p, q, U)
+    slack = b - A @ U
+    osc = max(1.0, np.abs(g).max() / 100.0)
+    m = len(b)
+    best = None
+    n_prev = -1
+    for thr in THRESHOLDS:
+        act = slack <= thr * np.maximum(1.0, np.abs(b))
+        if best is not None and ((thr >= WIDE_FROM and best[0] <= WIDE_IF_ABOVE) or int(act.sum()) == n_prev):
+            continue
+        n_prev = int(act.sum())
+        cands = [np.zeros(m)]
+        if act.any():
+            cands[0][act] = _nnls(A[act].T, -g)
+            pr = (cands[0] * slack)[act & (cands[0] > 0)]
+            if len(pr) and (~act).any() and slack[~act].min() > 0:
+                lam = np.zeros(m)
+                lam[~act] = np.median(pr) / slack[~act]
+                lam[act] = _nnls(A[act].T, -(g + A[~act].T @ lam[~act]))
+                cands.append(lam)
+        for lam in cands:
+            sd = max(100.0, lam.sum() / m) / 100.0
+            stat = np.abs(g + A.T @ lam).max() / (osc * sd)
+            comp = (lam * np.maximum(slack, 0.0)).max() / (osc * sd)
+            if best is None or max(stat, comp) < best[0]:
+                best = (max(stat, comp), lam, osc * sd, thr)
+    _, lam, scale, thr = best
+    c = O.certify(p, q, U, lam)   # the independent C evaluation of (U, lam)
+    c["scaled_stationarity"] = c["stationarity"] / scale
+    c["scaled_complementarity"] = c["complementarity"] / scale
+    ref_scale = scale / osc * max(1.0, np.abs(O.grad(p, q, np.zeros_like(U))).max() / 100.0)
+    c["ref_scaled_stationarity"] = c["stationarity"] / ref_scale
+    c["ref_scaled_complementarity"] = c["complementarity"] / ref_scale
+    c["threshold"] = thr
+    return c
+
+
+KEYS = ("scaled_stationarity", "scaled_complementarity", "ref_scaled_stationarity", "ref_scaled_complementarity", "stationarity", "violation", "lam_min", "complementarity", "cost", "threshold")
+
+
+def certify_batch(O, p, d, U, idx=None, **kw):
+    """-> dict of arrays over the certified problems (idx = indices into the batch, default all)"""
+    idx = np.arange(len(U)) if idx is None else np.asarray(idx)
+    out = {k: [] for k in KEYS}
+    for i in idx:
+        c = certify_one(O, p, d["z0"][i], d["ref"][i], d["v_target"][i], d["u_prev"][i], U[i], **kw)
+        for k in KEYS:
+            out[k].append(c[k])
+    return {k: np.array(v) for k, v in out.items()}
+
+
+def stratified_sample(iters, status, n, seed=0):
+    """indices of a sample of size <= n: non-Optimal problems (up to n/4), the n/8 problems with the most iterations, the rest uniform"""
+    B = len(iters)
+    if B <= n:
+        return np.arange(B)
+    rng = np.random.default_rng(seed)
+    bad = np.where(status != 0)[0][: n // 4]
+    top = np.argsort(-iters, kind="stable")[: n // 8]
+    pick = set(bad.tolist()) | set(top.tolist())
+    for i in rng.permutation(B):
+        if len(pick) >= n:
+            break
+        pick.add(int(i))
+    return np.array(sorted(pick))

@@ -72,9 +72,17 @@ def test_sim_kernel_matches_oracle():
     sim._update_vehicle_model(10)                       # one 10 Hz control period = 100 sub-steps
     got = sim.state.cpu().numpy()
     exp = V.update_vehicle_model(s0, cmd, n_updates=10)
-    assert np.abs(got[:, 0:2] - exp[:, 0:2]).max() < 1e-9
     dpsi = np.abs((got[:, 2] - exp[:, 2] + np.pi) % (2 * np.pi) - np.pi)   # a wrap at +-pi may land on either side
-    assert dpsi.max() < 1e-10 and np.abs(got[:, 3:] - exp[:, 3:]).max() < 1e-10
+    mv = s0[:, 3] > 0                                  # moving vehicles: rounding-level parity (libm sin/cos/atan2 differ by <= 1-2 ulp)
+    assert np.abs(got[mv, 0:2] - exp[mv, 0:2]).max() < 1e-9
+    assert dpsi[mv].max() < 1e-10 and np.abs(got[mv, 3:] - exp[mv, 3:]).max() < 1e-10
+    # standing starts: with the reference's (Python 2) integer division at vehicle_simulator.py:84 there is no lateral-force drag, so a
+    # car at rest with a positive acceleration pulls away through 0 < vx < 0.03 m/s, where the 1 ms explicit Euler step of the
+    # linear-tyre model is unstable (dt * (C_f + C_r) / (m vx) > 2): last-ulp differences of atan2 are amplified ~1e9-fold there.
+    # Same model, same trajectory to 1e-4 m / 1e-4 rad/s after the control period -- not rounding-level.
+    assert np.abs(got[~mv, 0:2] - exp[~mv, 0:2]).max() < 1e-4 and dpsi[~mv].max() < 1e-4
+    assert np.abs(got[~mv, 3:] - exp[~mv, 3:]).max() < 1e-3
+    assert (~mv).sum() > 100 and (exp[~mv, 3] > 0).sum() > 50   # the stratum is there and some of it does pull away
     assert (got[:, 3] >= 0).all()
 
 

@@ -160,6 +160,39 @@ def test_pipelined_solution_gather_gloo_world2():
     assert g.wait(0) is u
 
 
+def test_wire_types_mirror_the_msg_files():
+    """field names and order of msg/*.msg (the text of each file is three to nine `float64 name` lines) and the MD5 sums the
+    genmsg rule gives for them (unverified against a ROS install)"""
+    from dataclasses import fields
+    from mkz_mpc_path_follower_amd import messages as M
+    assert [f.name for f in fields(M.StateEst)] == ["header", "x", "y", "psi", "v", "lat", "lon", "a", "df"]     # msg/state_est.msg:1-9
+    assert [f.name for f in fields(M.MPCCmd)] == ["header", "accel_cmd", "steer_angle_cmd"]                     # msg/MPC_cmd.msg:1-3
+    assert [f.name for f in fields(M.MPCPath)] == ["header", "xs", "ys", "psis"]                                # msg/mpc_path.msg:1-4
+    assert [f.name for f in fields(M.AccStamped)] == ["header", "accel_value"]                                  # msg/acc_stamped.msg:1-2
+    assert M.ros_md5(M.MPCCmd) == "4cc9813360048599657ed07f1e3a49c7"
+    assert M.ros_md5(M.StateEst) == "3fc895b2d82deff841eec10883ba25f1"
+    assert M.ros_md5(M.MPCPath) == "bfa6be669d3684fb46eee30feac22a41"
+    assert M.ros_md5(M.AccStamped) == "55b5fb89b56deee865ea283fe7091d26"
+
+
+def test_spawn_ranks_launch_path(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself (dist.spawn_ranks: a torch.distributed.run child on
+    127.0.0.1, before any GPU call).  Same launcher, CPU child script, gloo: world size 2 arrives, the gathered block is right."""
+    import json
+    import sys
+    from mkz_mpc_path_follower_amd.dist import spawn_ranks
+    out = str(tmp_path / "probe.json")
+    rc = spawn_ranks(os.path.join(os.path.dirname(__file__), "_rank_probe.py"), 2, ["2", out], timeout=300)
+    assert rc == 0
+    assert json.load(open(out)) == {"n_gpus": 2, "ok": True}
+    # a rank count that does not match --gpus is refused rather than silently run on one GPU
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"), "--gpus", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
 def test_ros_adapter_topic_surface():
     """the rospy adapter reproduces mpc_cmd_pub.jl's node name, topics, queue sizes, 10 Hz rate, the one-shot
     `enable`, the rosparam checks and the stop latch -- checked against a stub rospy (ROS is not installed here) and a stub solver."""

@@ -85,6 +85,29 @@ def test_kernel_matches_oracle(path, traj, mode):
 
 
 @pytest.mark.gpu
+def test_non_finite_pose_is_contained(path, traj):
+    """A NaN / inf pose (GPS glitch, diverged plant) must not index outside the path: np.argmin of an all-NaN / all-inf distance
+    array is 0 (ref_gps_traj.py:172-173), so the kernel answers with the closest index 0 and keeps the rest of the batch intact."""
+    import torch
+    from oracle import waypoints as W
+    from mkz_mpc_path_follower_amd.ref_traj import GPSRefTrajectory
+    g = GPSRefTrajectory(arrays=dict(t=path["t"], lat=path["lat"], lon=path["lon"], psi=path["psi"]), traj_horizon=8)
+    tr = g.trajectory
+    pose = np.stack([tr[[100, 200, 300, 400, 500], 4], tr[[100, 200, 300, 400, 500], 5], tr[[100, 200, 300, 400, 500], 3]], axis=1)
+    pose[1, 0] = np.nan
+    pose[2, 1] = np.inf
+    pose[3, 0] = -np.inf
+    ref, stop, closest = g.get_waypoints_batch(pose, np.full(5, 5.0), want_closest=True)
+    torch.cuda.synchronize()
+    closest = closest.cpu().numpy()
+    assert list(closest) == [100, 0, 0, 0, 500]
+    for b in (0, 4):
+        xi, yi, pi_, st, ci = W.get_waypoints(tr, pose[b, 0], pose[b, 1], pose[b, 2], 5.0, traj_horizon=8)
+        assert np.abs(ref[b, :, 0].cpu().numpy() - xi).max() <= 1e-12 and ci == closest[b]
+    assert torch.isfinite(ref[1:4, :, :2]).all()   # waypoints from index 0 on: finite positions
+
+
+@pytest.mark.gpu
 def test_waypoints_feed_the_solver_closed_loop(path):
     """state -> waypoints kernel -> MPC kernel -> command, for a small fleet, all device-resident; then the
     reference's node loop on the real path until the stop latch (mpc_cmd_pub.jl:86-157)."""
