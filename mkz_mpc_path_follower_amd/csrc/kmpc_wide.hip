@@ -44,16 +44,18 @@ template <typename T, int N> struct WideSolver {
     // LDS map (elements of T)
     static constexpr int O_LC = 0, O_OPB = (LC + 1) & ~1, O_LIN = O_OPB + 2 * 8 * NP, O_XB = O_LIN + WLIN * (N + 1), O_WB = O_XB + 128,
                          O_CBW = O_WB + 256, O_RED = O_CBW + 4 * 64, O_SINV = O_RED + 2 * 32, O_X2 = O_SINV + 16 * NB, O_X3 = O_X2 + 128,
-                         O_GB = O_X3 + 128, O_PT = O_GB + 128, O_KC = O_PT + 32, O_END = O_KC + (sizeof(T) == 8 ? KC_COUNT : 0);
+                         O_GB = O_X3 + 128, O_UB = O_GB + 128, O_CS = O_UB + 128, O_PT = O_CS + 4 * 16, O_KC = O_PT + 32, O_END = O_KC + (sizeof(T) == 8 ? KC_COUNT : 0);
     static constexpr int lds_elems() { return O_END; }
 
+    STAMP_MEMBERS
     const KP &P;
-    int tid, lane, wv, R0, R1;
-    T *Lc, *opb, *pan, *dgs, *sbs, *lin, *xb, *wb, *cb, *red, *sinvb, *x2, *x3, *gbl;
+    int tid, lane, wv;
+    T *Lc, *opb, *pan, *dgs, *sbs, *lin, *xb, *wb, *cb, *red, *sinvb, *x2, *x3, *gbl, *ubl, *cs;
     Coef<T> kc;
     const T *pt, *cwt;
     int rpar;
-    T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
+    T psi0, v0, vt, rx, ry, rp;   // (x0 = y0 = 0 in vehicle-centred coordinates; u_prev and the offsets are re-read where they are used)
+    const T *z0p, *upp_;
     enum { PT_DT = 0, PT_DTC, PT_RR, PT_DT2, PT_DTL, PT_LB, PT_TOL, PT_GAP_TOL, PT_TOL_X100, PT_TOL_X1000, PT_TOL_D100, PT_TOL_D10,
            PT_STEER_MAX, PT_A_MAX, PT_STEER_DMAX, PT_A_DMAX, PT_W = 16, PT_V_MIN = 24, PT_V_MAX, PT_RELAX, PT_WARM_PUSH, PT_WARM_MU, PT_MU_INIT,
            PT_INV2NF };
@@ -61,11 +63,11 @@ template <typename T, int N> struct WideSolver {
     DEV WideSolver(const KP &p, unsigned char *smem) : P(p), tid(threadIdx.x), lane(threadIdx.x & 63), rpar(0)
     {
         wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        R0 = NTF - 1 - wv; R1 = wv - 1;
         T *base = reinterpret_cast<T *>(smem);
         Lc = base + O_LC; opb = base + O_OPB; lin = base + O_LIN; xb = base + O_XB; wb = base + O_WB;
         cb = base + O_CBW + 64 * wv;  // every wave keeps its OWN copy of the stage prefix / suffix sums: no barrier to share them
-        red = base + O_RED; sinvb = base + O_SINV; x2 = base + O_X2; x3 = base + O_X3; gbl = base + O_GB;
+        red = base + O_RED; sinvb = base + O_SINV; x2 = base + O_X2; x3 = base + O_X3; gbl = base + O_GB; ubl = base + O_UB;
+        cs = base + O_CS + 16 * wv;    // wave-uniform scalars that are read once or twice per iteration: every wave parks its own copy
         pan = opb;                      // the Cholesky panel (2 x 4 NP) and the 2 x n staging of build_tiles alias the condensing
         dgs = opb + 2 * 4 * NP; sbs = dgs + 128;  // staging buffer: the three are live one after the other
         static_assert(2 * 4 * NP + 256 <= 2 * 8 * NP, "aliases fit the fragment staging buffer");
@@ -89,10 +91,10 @@ template <typename T, int N> struct WideSolver {
     DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)
     {
         // vehicle-centred coordinates (the NLP is translation-invariant; see kmpc_fast.hip)
-        xoff = z0[4 * (size_t)b]; yoff = z0[4 * (size_t)b + 1]; x0 = (T)0; y0 = (T)0;
-        psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
+        z0p = z0 + 4 * (size_t)b; upp_ = upp + 2 * (size_t)b;
+        const T xoff = z0p[0], yoff = z0p[1];
+        psi0 = z0p[2]; v0 = z0p[3];
         vt = vtp[b];
-        up0 = upp[2 * (size_t)b]; up1 = upp[2 * (size_t)b + 1];
         rx = ry = rp = (T)0;
         if (lane <= N) {  // every wave keeps the reference at stage `lane`
             const T *r = ref + ((size_t)b * (N + 1) + lane) * 3;
@@ -132,7 +134,7 @@ template <typename T, int N> struct WideSolver {
         } else if (f < n + R) {
             const int r = f - n, jj = r & 1, kk = r >> 1;
             const T d = pt[jj ? PT_STEER_DMAX : PT_A_DMAX] * pt[kk == 0 ? PT_DTC : PT_DT];
-            const T u = kk == 0 ? (jj ? up1 : up0) : (T)0;
+            const T u = kk == 0 ? upp_[jj] : (T)0;
             bu = d + relax * fmax((T)1, d) + u; bl = d + relax * fmax((T)1, d) - u;
         } else if (f < nf) {
             const T vmax = pt[PT_V_MAX], vmin = pt[PT_V_MIN];
@@ -222,8 +224,8 @@ template <typename T, int N> struct WideSolver {
         S.s = sp * S.cosb + cp * S.sinb;
         const T wx = st ? v * S.c : (T)0, wy = st ? v * S.s : (T)0;
         const T ix = dpp_scan_prefix<SROWS>(wx), iy = dpp_scan_prefix<SROWS>(wy);
-        S.x = x0 + dt * (ix - wx);
-        S.y = y0 + dt * (iy - wy);
+        S.x = dt * (ix - wx);
+        S.y = dt * (iy - wy);
         S.v = v; S.psi = psi;
         const bool cs = (k >= 1 && k <= N);
         S.ex = cs ? S.x - rx : (T)0;
@@ -304,13 +306,17 @@ template <typename T, int N> struct WideSolver {
         r.a02 = q[0]; r.a03 = q[1]; r.a12 = q[2]; r.a13 = q[3]; r.a23 = q[4]; r.bx = q[5]; r.by = q[6]; r.bp = q[7];
         r.mpp = q[8]; r.mpv = q[9]; r.mpd = q[10]; r.mvd = q[11]; r.mdd = q[12];
     }
-    DEV void condense(T sc, acc_t (&k0)[NTF], acc_t (&k1)[3])
+    // Tile rows of wave W (compile-time in everything below: each wave runs its own specialisation, selected once per
+    // factorisation by a switch on the wave number; tile indices, liveness tests and register arrays are then all static)
+    template <int W> struct Rows { static constexpr int R0 = NTF - 1 - W, R1 = W - 1, N0 = R0 + 1, N1 = R1 >= 0 ? R1 + 1 : 1; };
+    template <int W> DEV void condense(T sc, acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
     {
+        constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1, N0 = Rows<W>::N0, N1 = Rows<W>::N1;
         const int kk = lane >> 4, c = lane & 15;
 #pragma unroll
-        for (int t = 0; t < NTF; ++t) k0[t] = acc_t{0, 0, 0, 0};
+        for (int t = 0; t < N0; ++t) k0[t] = acc_t{0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < 3; ++t) k1[t] = acc_t{0, 0, 0, 0};
+        for (int t = 0; t < N1; ++t) k1[t] = acc_t{0, 0, 0, 0};
         const bool colthr = tid < NP;               // this thread carries column `tid` of G
         const int col = tid;
         T gx = 0, gy = 0, gp = 0, gv = 0;
@@ -318,16 +324,19 @@ template <typename T, int N> struct WideSolver {
         const T gvnew = (col & 1) ? (T)0 : pt[PT_DT];
         T *colK = Lc + offc_rt(col < n ? col : 0);
         const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3];
-        T fa0 = 0, fa1 = 0, fb[NTF];
+        T fa0 = 0, fa1 = 0, fb[N0];
 #pragma unroll
-        for (int t = 0; t < NTF; ++t) fb[t] = (T)0;
-        Rec cur;
-        load_rec(cur, 0);
+        for (int t = 0; t < N0; ++t) fb[t] = (T)0;
 #pragma nounroll
         for (int s = 0; s < N; ++s) {
-            Rec nxt;
-            load_rec(nxt, s + 1);
+            // products of state s first (its fragments were fetched after the previous barrier; state 0 is identically zero): the
+            // recursion below runs in their shadow
+            mfma_state<W>(s, fa0, fa1, fb, k0, k1);
             if (colthr) {
+                Rec cur;
+                load_rec(cur, s);
+                const T *qn = lin + WLIN * (s + 1);   // record N is all zero (linearize)
+                const T nmpp = qn[8], nmpv = qn[9];
                 // odd row rho = 2s+1 of the image from G_s (zero second-order part when the Gauss-Newton matrix is wanted)
                 const int rho = 2 * s + 1;
                 const T val = sc * (cur.mpd * gp + cur.mvd * gv) + (col == rho ? sc * cur.mdd : (T)0);
@@ -342,17 +351,13 @@ template <typename T, int N> struct WideSolver {
                 gy = fma(ind, cur.by, gy);
                 gp = fma(ind, cur.bp, gp);
                 gv += isnew ? gvnew : (T)0;
-            }
-            // products of state s (its fragments were fetched after the previous barrier); state 0 is identically zero
-            mfma_state(s, fa0, fa1, fb, k0, k1);
-            if (colthr) {
                 const T Cv1 = s + 1 <= N - 1 ? Cv2 : (T)0;
                 T *o = opb + ((s + 1) & 1) * 8 * NP + col;
                 o[0 * NP] = gx; o[1 * NP] = gy; o[2 * NP] = gp; o[3 * NP] = gv;
                 o[4 * NP] = Cx2 * gx;
                 o[5 * NP] = Cy2 * gy;
-                o[6 * NP] = (Cp2 + nxt.mpp) * gp + nxt.mpv * gv;
-                o[7 * NP] = Cv1 * gv + nxt.mpv * gp;
+                o[6 * NP] = (Cp2 + nmpp) * gp + nmpv * gv;
+                o[7 * NP] = Cv1 * gv + nmpv * gp;
             }
             WGSYNC();
             // fragments of state s+1: columns < 2(s+1) are non-zero
@@ -364,25 +369,23 @@ template <typename T, int N> struct WideSolver {
                 if (l0) fa0 = o[kk * NP + 16 * R0 + c];
                 if (l1) fa1 = o[kk * NP + 16 * R1 + c];
 #pragma unroll
-                for (int t = 0; t < NTF; ++t)
+                for (int t = 0; t < N0; ++t)
                     if (t <= tmax) fb[t] = o[(4 + kk) * NP + 16 * t + c];
             }
-            cur = nxt;
         }
-        mfma_state(N, fa0, fa1, fb, k0, k1);
+        mfma_state<W>(N, fa0, fa1, fb, k0, k1);
     }
-    DEV void mfma_state(int s, T fa0, T fa1, const T (&fb)[NTF], acc_t (&k0)[NTF], acc_t (&k1)[3])
+    template <int W> DEV void mfma_state(int s, T fa0, T fa1, const T (&fb)[Rows<W>::N0], acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
     {
+        constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
         const int cols = 2 * s;
         if (16 * R0 < cols) {
 #pragma unroll
-            for (int t = 0; t < NTF; ++t)
-                if (t <= R0) k0[t] = Real<T>::mfma(fa0, fb[t], k0[t]);
+            for (int t = 0; t <= R0; ++t) k0[t] = Real<T>::mfma(fa0, fb[t], k0[t]);
         }
         if (R1 >= 0 && 16 * R1 < cols) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                if (t <= R1) k1[t] = Real<T>::mfma(fa1, fb[t], k1[t]);
+            for (int t = 0; t <= R1; ++t) k1[t] = Real<T>::mfma(fa1, fb[t], k1[t]);
         }
     }
 
@@ -416,8 +419,9 @@ template <typename T, int N> struct WideSolver {
             }
         }
     }
-    DEV void build_tiles(T sc, T reg, acc_t (&k0)[NTF], acc_t (&k1)[3])
+    template <int W> DEV void build_tiles(T sc, T reg, acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
     {
+        constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
         if (tid < n) {
             const int j = tid, jj = j & 1, k = j >> 1;
             const T Cu2 = cwt[jj ? 7 : 6], Cdl2 = cwt[jj ? 5 : 4];
@@ -430,35 +434,48 @@ template <typename T, int N> struct WideSolver {
             sbs[j] = -wr - sc * Cdl2;
         }
         WGSYNC();
-        build_row<NTF>(sc, R0, k0);
-        if (R1 >= 0) build_row<3>(sc, R1, k1);
+        build_row<Rows<W>::N0>(sc, R0, k0);
+        if (R1 >= 0) build_row<Rows<W>::N1>(sc, R1, k1);
         WGSYNC();  // dgs / sbs / the odd rows of the image have been consumed: the panel and the factor may overwrite them
     }
 
     // ---- blocked Cholesky on the matrix cores (block-LDL^T form, see kmpc_fast.hip), one barrier per 4-column block-step ---------
-    DEV void extract_panel(int jb, const acc_t (&k0)[NTF], const acc_t (&k1)[3])
+    template <int W> DEV void extract_panel(int jb, const acc_t (&k0)[Rows<W>::N0], const acc_t (&k1)[Rows<W>::N1])
     {
+        constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
         const int c = lane & 15, j0 = 4 * jb, tcol = j0 >> 4, kp = c - (j0 & 15);
         T *pn = pan + (jb & 1) * 4 * NP;
+        // the tile of column tcol is picked by VALUE selects: a branch per tile column ends, after the optimiser's block merging, in a
+        // phi over the addresses of the tile registers, which keeps every tile in scratch memory
+        acc_t v0 = k0[0], v1 = k1[0];
+#pragma unroll
+        for (int tc = 1; tc <= R0; ++tc) {
+            const bool hit = tcol == tc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v0[r] = hit ? k0[tc][r] : v0[r];
+        }
+#pragma unroll
+        for (int tc = 1; tc <= R1; ++tc) {
+            const bool hit = tcol == tc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v1[r] = hit ? k1[tc][r] : v1[r];
+        }
         if (kp >= 0 && kp < 4) {
+            if (tcol <= R0) {
 #pragma unroll
-            for (int tc = 0; tc < NTF; ++tc)
-                if (tc == tcol) {
-                    if (R0 >= tc) {
+                for (int r = 0; r < 4; ++r) pn[4 * (16 * R0 + Real<T>::row_of(lane, r)) + kp] = v0[r];
+            }
+            if (R1 >= 0 && tcol <= R1) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pn[4 * (16 * R0 + Real<T>::row_of(lane, r)) + kp] = k0[tc][r];
-                    }
-                    if (tc < 3 && R1 >= tc) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) pn[4 * (16 * R1 + Real<T>::row_of(lane, r)) + kp] = k1[tc < 3 ? tc : 0][r];
-                    }
-                }
+                for (int r = 0; r < 4; ++r) pn[4 * (16 * R1 + Real<T>::row_of(lane, r)) + kp] = v1[r];
+            }
         }
     }
-    DEV bool factor(acc_t (&k0)[NTF], acc_t (&k1)[3])
+    template <int W> DEV bool factor(acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
     {
+        constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
         const int c = lane & 15, kk = lane >> 4;
-        extract_panel(0, k0, k1);
+        extract_panel<W>(0, k0, k1);
         WGSYNC();
         bool ok = true;
 #pragma nounroll
@@ -468,11 +485,7 @@ template <typename T, int N> struct WideSolver {
             const T *pd = pn + 4 * j0;
             const T d00 = pd[0], d10 = pd[4], d11 = pd[5], d20 = pd[8], d21 = pd[9], d22 = pd[10];
             const T d30 = pd[12], d31 = pd[13], d32 = pd[14], d33 = pd[15];
-            T a[NTF][4], aa0[4], aa1[4];
-#pragma unroll
-            for (int t = 0; t < NTF; ++t)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a[t][k] = t >= tcol ? pn[4 * (16 * t + c) + k] : (T)0;
+            T aa0[4], aa1[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { aa0[k] = pn[4 * (16 * R0 + c) + k]; aa1[k] = pn[4 * (16 * (R1 >= 0 ? R1 : 0) + c) + k]; }
             const T r0 = rsqrt_(d00);
@@ -502,14 +515,18 @@ template <typename T, int N> struct WideSolver {
 #pragma unroll
             for (int t = 0; t < NTF; ++t) {
                 const int row = 16 * t + c;
-                const T x0_ = a[t][0] * r0;
-                const T x1_ = fma(-x0_, l10, a[t][1]) * r1;
-                const T x2_ = fma(-x1_, l21, fma(-x0_, l20, a[t][2])) * r2;
-                const T x3_ = fma(-x2_, l32, fma(-x1_, l31, fma(-x0_, l30, a[t][3]))) * r3;
+                pf[t] = (T)0;
+                if (!(t <= R0 || (t & 3) == W)) continue;   // neither a B fragment of this wave's tiles nor a tile row whose L~ entries it stores
+                if (t < tcol) continue;                      // finished tile rows (wave-uniform)
+                const T *ar = pn + 4 * row;
+                const T x0_ = ar[0] * r0;
+                const T x1_ = fma(-x0_, l10, ar[1]) * r1;
+                const T x2_ = fma(-x1_, l21, fma(-x0_, l20, ar[2])) * r2;
+                const T x3_ = fma(-x2_, l32, fma(-x1_, l31, fma(-x0_, l30, ar[3]))) * r3;
                 const T xs = kk == 0 ? x0_ : (kk == 1 ? x1_ : (kk == 2 ? x2_ : x3_));
-                const bool live = t >= tcol && row >= jc && row <= n;
+                const bool live = row >= jc && row <= n;
                 pf[t] = live ? xs : (T)0;                       // component kk of L (B fragment of the trailing update)
-                if (live && (t & 3) == wv) colL[row] = fma(x3_, c3, fma(x2_, c2, fma(x1_, c1, x0_ * c0)));  // component kk of L~ = L D^-1
+                if (live && (t & 3) == W) colL[row] = fma(x3_, c3, fma(x2_, c2, fma(x1_, c1, x0_ * c0)));  // component kk of L~ = L D^-1
             }
             {
                 const int row = 16 * R0 + c;
@@ -533,19 +550,43 @@ template <typename T, int N> struct WideSolver {
                 const int tmin = (j0 + 4) >> 4;  // first tile column that still has live entries
                 if (R0 >= tmin) {
 #pragma unroll
-                    for (int t = 0; t < NTF; ++t)
-                        if (t >= tmin && t <= R0) k0[t] = Real<T>::mfma(pa0, -pf[t], k0[t]);
+                    for (int t = 0; t <= R0; ++t)
+                        if (t >= tmin) k0[t] = Real<T>::mfma(pa0, -pf[t], k0[t]);
                 }
                 if (R1 >= tmin) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
-                        if (t >= tmin && t <= R1) k1[t] = Real<T>::mfma(pa1, -pf[t], k1[t]);
+                    for (int t = 0; t <= R1; ++t)
+                        if (t >= tmin) k1[t] = Real<T>::mfma(pa1, -pf[t], k1[t]);
                 }
-                extract_panel(jb + 1, k0, k1);
+                extract_panel<W>(jb + 1, k0, k1);
             }
             WGSYNC();
         }
         return ok;
+    }
+
+    // condense + (max |sc H_jj|) + KKT assembly + factorisation for the tile rows of wave W
+    template <int W> DEV bool assemble_factor(T sc, T reg, bool want_hmax, T &hmax)
+    {
+        constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
+        acc_t k0[Rows<W>::N0], k1[Rows<W>::N1];
+        condense<W>(sc, k0, k1);
+        STAMP(3);
+        if (want_hmax) {  // max |sc * H_jj|: scale of the delta_w shift (diagonal tiles (R0, R0) and (R1, R1))
+            T hm = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (Real<T>::row_of(lane, r) == (lane & 15)) {
+                    if (16 * R0 + (lane & 15) < n) hm = fmax(hm, fabs(sc * k0[R0][r]));
+                    if (R1 >= 0) hm = fmax(hm, fabs(sc * k1[R1 >= 0 ? R1 : 0][r]));
+                }
+            T dm[1] = {(T)0}, hx[1] = {hm};
+            wg_reduce<0, 1>(dm, hx);
+            hmax = hx[0];
+        }
+        build_tiles<W>(sc, reg, k0, k1);
+        STAMP(4);
+        return factor<W>(k0, k1);
     }
 
     // ---- substitutions on the block-LDL^T factor, in wave 0 with two slots per lane (j = lane, 64 + lane) ----------------------------
@@ -660,7 +701,7 @@ template <typename T, int N> struct WideSolver {
         for (int j = 0; j < 2; ++j) {
             const T ub = j ? steer_max : a_max;
             const T d0 = (j ? steer_dmax : a_dmax) * dtc;
-            const T up = j ? up1 : up0;
+            const T up = upp_[j];
             T lo = fmax(-ub - relax * fmax((T)1, ub), up - d0 - relax * fmax((T)1, d0));
             T hi = fmin(ub + relax * fmax((T)1, ub), up + d0 + relax * fmax((T)1, d0));
             if (j == 0) {
@@ -698,10 +739,14 @@ template <typename T, int N> struct WideSolver {
         const bool warm = P.warm != 0;
         const bool exact = P.hessian == 1;
         const bool fv = tid < nf;
-        T U, Ut, du = 0, g = 0, ubest = 0;
+        T U, Ut, du = 0;
         T sup = 0, slo = 0, isu = 0, isl = 0, lu = 0, ll = 0, aut = 0, cu_ = 0, cl_ = 0;  // one form per thread; cu_/cl_: corrector terms
         int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
-        T c_err = (T)1e30, c_rds = 0, c_dwl = 0, c_dws = 0, c_hmax = 0, c_muf = 0, c_phi0 = 0, c_dphi = 0, c_ad = 0, c_j = 0, c_lgs = 0, c_jp = (T)1e30;
+        // wave-uniform scalars that are read once or twice per iteration live in this wave's LDS slots, not in VGPRs (every lane
+        // stores the same value; a wave's LDS operations execute in program order)
+        enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J, C_LGS, C_JP };
+        cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_MUF] = 0; cs[C_PHI0] = 0; cs[C_DPHI] = 0;
+        cs[C_AD] = 0; cs[C_J] = 0; cs[C_LGS] = 0; cs[C_JP] = (T)1e30;
         int indef = indef_cfg == 2 ? 0 : indef_cfg, n_fail = 0;
         bool have_best = false;
         T mu = pt[warm ? PT_WARM_MU : PT_MU_INIT], sc = 1, Jt = 0, alpha = 0, reg = 0;
@@ -710,16 +755,16 @@ template <typename T, int N> struct WideSolver {
         const bool pc = P.mu_strategy == 1;
         bool corr_active = false, first_attempt = true, tiny_stop = false;
         int n_tiny = 0, n_flat = 0;
-        bool final_reuse = false;
         int mode = FIRST;
         StageW<T> St;
+        STAMP_DECL
         {
             T Uf;
             const bool feas = interior_point(Uf);
             if (!feas) {
                 status = 2;
                 const T ub = pt[(tid & 1) ? PT_STEER_MAX : PT_A_MAX];
-                U = tid < n ? fmin(fmax((tid & 1) ? up1 : up0, -ub), ub) : (T)0;
+                U = tid < n ? fmin(fmax(upp_[tid & 1], -ub), ub) : (T)0;
                 mode = FINAL;
             } else if (warm && io.warmU) {
                 const T dw = tid < n ? io.warmU[(size_t)b * n + tid] - Uf : (T)0;
@@ -739,12 +784,14 @@ template <typename T, int N> struct WideSolver {
             } else U = Uf;
         }
         Ut = U;
+        STAMP(0);
 #pragma nounroll
         for (;;) {
-            if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && c_err <= pt[PT_TOL])) {
-                Ut = ubest; U = Ut; status = 0; final_reuse = false;
+            if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && cs[C_ERR] <= pt[PT_TOL])) {
+                Ut = ubl[tid & 127]; U = Ut; status = 0;
             }
-            if (mode != REFACTOR && mode != RESTEP && !final_reuse) Jt = eval(Ut, St);
+            if (mode != REFACTOR && mode != RESTEP) Jt = eval(Ut, St);
+            STAMP(9);
             if (mode == FINAL) break;
             if (mode == TRIAL) {
                 const T a_ = sup - alpha * aut, b_ = slo + alpha * aut;
@@ -755,9 +802,9 @@ template <typename T, int N> struct WideSolver {
                 const bool okp = mx[0] == (T)0;
                 const T slg = sm[0];
                 const T phi = sc * Jt - mu * slg;
-                if (!(okp && phi - c_phi0 - (T)10 * Real<T>::eps() * fabs(c_phi0) <= eta_phi * alpha * c_dphi)) {
+                if (!(okp && phi - cs[C_PHI0] - (T)10 * Real<T>::eps() * fabs(cs[C_PHI0]) <= eta_phi * alpha * cs[C_DPHI])) {
                     if (corr_active) { mode = RESTEP; Ut = U; continue; }
-                    if (++ls >= max_ls) { status = c_err <= pt[PT_TOL_X100] ? 0 : 3; mode = FINAL; Ut = U; continue; }
+                    if (++ls >= max_ls) { status = cs[C_ERR] <= pt[PT_TOL_X100] ? 0 : 3; mode = FINAL; Ut = U; continue; }
                     alpha *= (T)0.5;
                     Ut = U + alpha * du;
                     continue;
@@ -765,13 +812,13 @@ template <typename T, int N> struct WideSolver {
                 {
                     const T stepn = mx[1], umax = fmax((T)1, mx[2]);
                     n_tiny = stepn <= (T)10 * Real<T>::eps() * umax ? n_tiny + 1 : 0;
-                    if (n_tiny >= 2) { U = Ut; status = c_err <= pt[PT_TOL_X1000] ? 0 : 3; tiny_stop = true; mode = FINAL; final_reuse = true; continue; }
+                    if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= pt[PT_TOL_X1000] ? 0 : 3; tiny_stop = true; mode = FINAL; continue; }
                 }
-                c_lgs = slg;
+                cs[C_LGS] = slg;
                 {
                     const T su = sup, sl = slo;
-                    lu += c_ad * ((mu - cu_ - lu * su) * isu + lu * isu * aut);
-                    ll += c_ad * ((mu - cl_ - ll * sl) * isl - ll * isl * aut);
+                    lu += cs[C_AD] * ((mu - cu_ - lu * su) * isu + lu * isu * aut);
+                    ll += cs[C_AD] * ((mu - cl_ - ll * sl) * isl - ll * isl * aut);
                     sup = su - alpha * aut;
                     slo = sl + alpha * aut;
                     isu = fv ? rcp_(sup) : (T)0; isl = fv ? rcp_(slo) : (T)0;
@@ -780,8 +827,9 @@ template <typename T, int N> struct WideSolver {
             const bool restep = mode == RESTEP;
             if (!restep) {
                 if (mode != REFACTOR) {
-                    U = Ut; c_j = Jt;
-                    g = linearize(St, exact && gn_hold == 0);
+                    U = Ut; cs[C_J] = Jt;
+                    const T g = linearize(St, exact && gn_hold == 0);
+                    STAMP(1);
                     if (mode == FIRST) {
                         const T w0 = forms_apply(U);
                         T bu_, bl_;
@@ -791,7 +839,7 @@ template <typename T, int N> struct WideSolver {
                         T sm[1] = {fv ? log_pos(sup * slo, kc) : (T)0};
                         T mx[1] = {fabs(g)};
                         wg_reduce<1, 1>(sm, mx);
-                        c_lgs = sm[0];
+                        cs[C_LGS] = sm[0];
                         const T gm = mx[0];
                         sc = gm > (T)100 ? (T)100 / gm : (T)1;  // Ipopt nlp_scaling_max_gradient
                         lu = mu * isu; ll = mu * isl;
@@ -799,7 +847,7 @@ template <typename T, int N> struct WideSolver {
                         lu = fmax(fmin(lu, kappa_sigma * mu * isu), mu * isu * ((T)1 / kappa_sigma));
                         ll = fmax(fmin(ll, kappa_sigma * mu * isl), mu * isl * ((T)1 / kappa_sigma));
                     }
-                    if (iters >= max_iter) { mode = FINAL; Ut = U; final_reuse = true; continue; }
+                    if (iters >= max_iter) { mode = FINAL; Ut = U; continue; }
                     ++iters;
                     const T rd = sc * g + forms_applyT(lu - ll);
                     const T cuv = sup * lu, clv = slo * ll;
@@ -812,19 +860,19 @@ template <typename T, int N> struct WideSolver {
                     const T err0 = fmax(rdm, cm0) * isd;
                     const T tol = pt[PT_TOL];
                     const T gap_lim = pt[PT_GAP_TOL] * fmax((T)1, fabs(Jt));
-                    c_err = err0; c_rds = rdm * isd;
+                    cs[C_ERR] = err0; cs[C_RDS] = rdm * isd;
                     bool done = false;
-                    if (err0 <= tol) { ubest = U; have_best = true; }
+                    if (err0 <= tol) { if (tid < 128) ubl[tid] = U; have_best = true; }
                     if (err0 <= tol) {
                         if (gap <= gap_lim * sc || n_polish >= 1) done = true; else ++n_polish;
                     } else if (n_polish > 0 && ++n_polish > 1) done = true;
                     n_accept = err0 <= pt[PT_TOL_X100] ? n_accept + 1 : 0;
-                    n_flat = fabs(Jt - c_jp) <= (T)20 * Real<T>::eps() * fmax((T)1, fabs(Jt)) ? n_flat + 1 : 0;
-                    c_jp = Jt;
+                    n_flat = fabs(Jt - cs[C_JP]) <= (T)20 * Real<T>::eps() * fmax((T)1, fabs(Jt)) ? n_flat + 1 : 0;
+                    cs[C_JP] = Jt;
                     if (n_flat >= 12 && err0 <= pt[PT_TOL_X1000]) done = true;
-                    if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; final_reuse = true; continue; }
+                    if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; continue; }
                     const T mu_min = fmax(pt[PT_TOL_D100], fmin(pt[PT_TOL_D10], (T)0.1 * gap_lim * sc * inv2nf));
-                    c_muf = mu_min;
+                    cs[C_MUF] = mu_min;
 #pragma nounroll
                     for (; !pc;) {  // monotone barrier update (mu_strategy 0)
                         T dm[1] = {(T)0}, cm[1] = {fv ? fmax(fabs(sup * lu - mu), fabs(slo * ll - mu)) : (T)0};
@@ -834,36 +882,31 @@ template <typename T, int N> struct WideSolver {
                     }
                     use_exact = exact && gn_hold == 0; reg = 0; attempt = 0;
                     if (gn_hold > 0) --gn_hold;
-                    if (use_exact && indef == 1 && c_dws > (T)0) { reg = c_dws / (T)3; if (reg < (T)1e-9 * c_hmax) reg = 0; }
+                    if (use_exact && indef == 1 && cs[C_DWS] > (T)0) { reg = cs[C_DWS] / (T)3; if (reg < (T)1e-9 * cs[C_HMAX]) reg = 0; }
                     first_attempt = true;
+                    STAMP(2);
                 }
                 // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
                 stage_form_weights(lu * isu + ll * isl);
+                STAMP(6);
                 bool factored;
                 {
-                    acc_t k0[NTF], k1[3];
-                    condense(sc, k0, k1);
-                    if (use_exact && indef == 1 && first_attempt) {  // max |sc * H_jj|: scale of the delta_w shift
-                        T hm = 0;
-#pragma unroll
-                        for (int t = 0; t < NTF; ++t)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if (t == R0 && Real<T>::row_of(lane, r) == (lane & 15) && 16 * t + (lane & 15) < n) hm = fmax(hm, fabs(sc * k0[t][r]));
-                                if (t < 3 && t == R1 && Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * k1[t < 3 ? t : 0][r]));
-                            }
-                        T dm[1] = {(T)0}, hx[1] = {hm};
-                        wg_reduce<0, 1>(dm, hx);
-                        c_hmax = hx[0];
+                    const bool want_hmax = use_exact && indef == 1 && first_attempt;
+                    T hmax = cs[C_HMAX];
+                    switch (wv) {   // every wave runs the specialisation for its tile rows; the barriers inside pair up across them
+                        case 0: factored = assemble_factor<0>(sc, reg, want_hmax, hmax); break;
+                        case 1: factored = assemble_factor<1>(sc, reg, want_hmax, hmax); break;
+                        case 2: factored = assemble_factor<2>(sc, reg, want_hmax, hmax); break;
+                        default: factored = assemble_factor<3>(sc, reg, want_hmax, hmax); break;
                     }
+                    cs[C_HMAX] = hmax;
                     first_attempt = false;
-                    build_tiles(sc, reg, k0, k1);
-                    factored = factor(k0, k1);
                 }
+                STAMP(5);
                 if (!factored) {
-                    if (++attempt >= 40) { status = 3; mode = FINAL; Ut = U; final_reuse = true; continue; }
+                    if (++attempt >= 40) { status = 3; mode = FINAL; Ut = U; continue; }
                     if (use_exact && indef == 1) {
-                        const T hmax = c_hmax, dw_last = c_dwl;
+                        const T hmax = cs[C_HMAX], dw_last = cs[C_DWL];
                         if (reg == (T)0) reg = dw_last > (T)0 ? fmax((T)1e-10 * hmax, dw_last / (T)3) : (T)1e-2 * hmax;
                         else reg *= dw_last > (T)0 ? (T)8 : (T)10;
                         if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; drop_second_order(); }
@@ -874,8 +917,8 @@ template <typename T, int N> struct WideSolver {
                     mode = REFACTOR; Ut = U;
                     continue;
                 }
-                if (use_exact && reg > (T)0) c_dwl = reg;
-                if (use_exact) c_dws = reg;
+                if (use_exact && reg > (T)0) cs[C_DWL] = reg;
+                if (use_exact) cs[C_DWS] = reg;
                 cu_ = cl_ = (T)0;
                 corr_active = false;
                 if (pc) {
@@ -894,9 +937,10 @@ template <typename T, int N> struct WideSolver {
                     wg_reduce<1, 0>(sa, dm);
                     const T mucur = sm[0] * pt[PT_INV2NF], muaff = sa[0] * pt[PT_INV2NF];
                     const T r3 = muaff * rcp_(mucur);
-                    mu = fmax(c_muf, fmin((T)1, r3 * r3 * r3) * mucur);
-                    mu = fmax(mu, fmin(mucur, c_rds * (T)KMPC_IKRD));  // no barrier target far below the dual infeasibility
+                    mu = fmax(cs[C_MUF], fmin((T)1, r3 * r3 * r3) * mucur);
+                    mu = fmax(mu, fmin(mucur, cs[C_RDS] * (T)KMPC_IKRD));  // no barrier target far below the dual infeasibility
                     corr_active = true;
+                    STAMP(7);
                 }
             } else {  // RESTEP: same factor, corrector term dropped
                 cu_ = cl_ = (T)0;
@@ -904,6 +948,7 @@ template <typename T, int N> struct WideSolver {
             }
             // centering (+ corrector) part of the step: du = K^{-1}(-sc*g - A^T((mu - corr)/s_u - (mu - corr)/s_l))
             du = solve_dir(forms_applyT(-((mu - cu_) * isu - (mu - cl_) * isl)), true);
+            STAMP(15);
             aut = forms_apply(du);
             const T tau = fmax(tau_min, (T)1 - mu);
             {
@@ -916,19 +961,21 @@ template <typename T, int N> struct WideSolver {
                     rp_ = fmax(-dsu * isu, -dsl * isl);
                     rq_ = fmax(-dlu * rcp_(lu), -dll * rcp_(ll));
                 }
-                T sm[1] = {(tid < n ? sc * g * du : (T)0) + gw};
+                T sm[1] = {(tid < n ? sc * gbl[tid] * du : (T)0) + gw};
                 T mx[2] = {fmax(rp_, (T)0), fmax(rq_, (T)0)};
                 wg_reduce<1, 2>(sm, mx);
                 // fraction to the boundary: alpha = min(1, tau * min(-s/ds)) = tau / max(tau, max(-ds/s))
                 const T ap = tau * rcp_(fmax(tau, mx[0]));
-                c_ad = tau * rcp_(fmax(tau, mx[1]));
-                c_phi0 = sc * c_j - mu * c_lgs;
-                c_dphi = sm[0];
+                cs[C_AD] = tau * rcp_(fmax(tau, mx[1]));
+                cs[C_PHI0] = sc * cs[C_J] - mu * cs[C_LGS];
+                cs[C_DPHI] = sm[0];
                 alpha = ap; ls = 0;
             }
             Ut = U + alpha * du;
             mode = TRIAL;
+            STAMP(8);
         }
+        STAMP(10);
         // ---- outputs (St / Jt are the evaluation of the returned U) ------------------------------------
         const T w0 = forms_apply(U);
         T vi[1] = {-(T)1e30}, dm[1] = {(T)0};
@@ -945,8 +992,10 @@ template <typename T, int N> struct WideSolver {
         }
         if (io.outX && tid <= N) {
             T *o = io.outX + ((size_t)b * (N + 1) + tid) * 4;
-            o[0] = St.x + xoff; o[1] = St.y + yoff; o[2] = St.psi; o[3] = St.v;
+            o[0] = St.x + z0p[0]; o[1] = St.y + z0p[1]; o[2] = St.psi; o[3] = St.v;
         }
+        STAMP(11);
+        STAMP_OUT(io.stamps, b);
         if (tid == 0) {
             io.status[b] = status;
             if (io.cost) io.cost[b] = Jt;

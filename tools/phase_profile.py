@@ -10,13 +10,14 @@ from mkz_mpc_path_follower_amd import BatchMPC
 from mkz_mpc_path_follower_amd.synthetic import make_batch
 NAMES = ["setup", "linearize", "residual+mu", "condense", "build_K", "chol:backsub", "rhs", "predictor", "step+ftb", "eval+trial", "exit", "outputs", "chol:sweep1", "chol:schur", "chol:sweep2", "corr solve"]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+CFG = 5 if N == 50 else 2
 for B in (1, 4096):
     s = BatchMPC(N=N)
     L = _lib.load()
     st = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
     L.kmpc_debug_set_stamps.argtypes = [C.c_void_p]
     L.kmpc_debug_set_stamps(C.c_void_p(st.data_ptr()))
-    d = make_batch(B, N, cfg_id=2)
+    d = make_batch(B, N, cfg_id=CFG)
     o = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"])
     torch.cuda.synchronize()
     it = o["iters"].double().cpu().numpy()
@@ -31,7 +32,7 @@ B = 4096
 s = BatchMPC(N=N)
 st = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
 L.kmpc_debug_set_stamps(C.c_void_p(st.data_ptr()))
-d = make_batch(B, N, cfg_id=2)
+d = make_batch(B, N, cfg_id=CFG)
 o = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"])
 torch.cuda.synchronize()
 it = o["iters"].cpu().numpy(); c = st.cpu().numpy().astype(np.float64); tot = c.sum(1)
