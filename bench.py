@@ -163,6 +163,8 @@ def kernel_name(N, dtype):
     t = "double" if dtype == "f64" else "float"
     if N in (8, 12, 16, 20, 24, 28):
         return "kmpc_solve_fast_kernel<%s,%d>" % (t, N)
+    if N == 50 and dtype == "f64":
+        return "kmpc_solve_wide_kernel<double,50>"
     return "kmpc_solve_kernel<%s>" % t
 
 

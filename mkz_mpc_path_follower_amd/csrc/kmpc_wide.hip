@@ -329,9 +329,6 @@ template <typename T, int N> struct WideSolver {
         for (int t = 0; t < N0; ++t) fb[t] = (T)0;
 #pragma nounroll
         for (int s = 0; s < N; ++s) {
-            // products of state s first (its fragments were fetched after the previous barrier; state 0 is identically zero): the
-            // recursion below runs in their shadow
-            mfma_state<W>(s, fa0, fa1, fb, k0, k1);
             if (colthr) {
                 Rec cur;
                 load_rec(cur, s);
@@ -359,6 +356,9 @@ template <typename T, int N> struct WideSolver {
                 o[6 * NP] = (Cp2 + nmpp) * gp + nmpv * gv;
                 o[7 * NP] = Cv1 * gv + nmpv * gp;
             }
+            // products of state s (state 0 is identically zero): its fragments were requested after the previous barrier and have
+            // landed while the recursion ran; nothing in the trip waits for the matrix cores
+            mfma_state<W>(s, fa0, fa1, fb, k0, k1);
             WGSYNC();
             // fragments of state s+1: columns < 2(s+1) are non-zero
             {
@@ -485,9 +485,6 @@ template <typename T, int N> struct WideSolver {
             const T *pd = pn + 4 * j0;
             const T d00 = pd[0], d10 = pd[4], d11 = pd[5], d20 = pd[8], d21 = pd[9], d22 = pd[10];
             const T d30 = pd[12], d31 = pd[13], d32 = pd[14], d33 = pd[15];
-            T aa0[4], aa1[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { aa0[k] = pn[4 * (16 * R0 + c) + k]; aa1[k] = pn[4 * (16 * (R1 >= 0 ? R1 : 0) + c) + k]; }
             const T r0 = rsqrt_(d00);
             const T l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
             const T e11 = fma(-l10, l10, d11), r1 = rsqrt_(e11);
@@ -511,7 +508,7 @@ template <typename T, int N> struct WideSolver {
             const T c3 = kk == 0 ? i30 : (kk == 1 ? i31 : (kk == 2 ? i32 : r3));
             const int jc = j0 + kk;
             T *colL = Lc + offc_rt(jc < n ? jc : 0);
-            T pf[NTF], pa0, pa1;
+            T pf[NTF];
 #pragma unroll
             for (int t = 0; t < NTF; ++t) {
                 const int row = 16 * t + c;
@@ -528,24 +525,8 @@ template <typename T, int N> struct WideSolver {
                 pf[t] = live ? xs : (T)0;                       // component kk of L (B fragment of the trailing update)
                 if (live && (t & 3) == W) colL[row] = fma(x3_, c3, fma(x2_, c2, fma(x1_, c1, x0_ * c0)));  // component kk of L~ = L D^-1
             }
-            {
-                const int row = 16 * R0 + c;
-                const T x0_ = aa0[0] * r0;
-                const T x1_ = fma(-x0_, l10, aa0[1]) * r1;
-                const T x2_ = fma(-x1_, l21, fma(-x0_, l20, aa0[2])) * r2;
-                const T x3_ = fma(-x2_, l32, fma(-x1_, l31, fma(-x0_, l30, aa0[3]))) * r3;
-                const T xs = kk == 0 ? x0_ : (kk == 1 ? x1_ : (kk == 2 ? x2_ : x3_));
-                pa0 = (row >= jc && row <= n) ? xs : (T)0;
-            }
-            {
-                const int row = 16 * R1 + c;
-                const T x0_ = aa1[0] * r0;
-                const T x1_ = fma(-x0_, l10, aa1[1]) * r1;
-                const T x2_ = fma(-x1_, l21, fma(-x0_, l20, aa1[2])) * r2;
-                const T x3_ = fma(-x2_, l32, fma(-x1_, l31, fma(-x0_, l30, aa1[3]))) * r3;
-                const T xs = kk == 0 ? x0_ : (kk == 1 ? x1_ : (kk == 2 ? x2_ : x3_));
-                pa1 = (R1 >= 0 && row >= jc && row <= n) ? xs : (T)0;
-            }
+            // the A fragment of tile row R is the B fragment of tile column R (same rows of the solved panel)
+            const T pa0 = pf[R0], pa1 = pf[R1 >= 0 ? R1 : 0];
             if (j0 + 4 < n) {
                 const int tmin = (j0 + 4) >> 4;  // first tile column that still has live entries
                 if (R0 >= tmin) {

@@ -38,7 +38,7 @@ def test_known_answers(oracle, N):
 
 @pytest.mark.parametrize("N,B", [(8, 64), (20, 256), (50, 32), (12, 128), (16, 128), (24, 128), (28, 128), (13, 64)])
 def test_batch_matches_oracle_fp64(oracle, N, B):
-    """compile-time-horizon kernel for N in {8, 12, 16, 20, 24, 28}, generic kernel for the rest (13, 50)"""
+    """compile-time-horizon kernel for N in {8, 12, 16, 20, 24, 28}, four-wave kernel for N = 50, generic kernel for the rest (13)"""
     O = oracle
     d = make_batch(B, N, cfg_id=2)
     r = _solve(N, d)
@@ -55,9 +55,10 @@ def test_batch_matches_oracle_fp64(oracle, N, B):
     assert abs(r["iters"].mean() - ro["iters"].mean()) < 1.0
 
 
-@pytest.mark.parametrize("N", [8, 12, 16, 24, 28])
+@pytest.mark.parametrize("N", [8, 12, 16, 24, 28, 50])
 def test_fast_and_generic_kernels_agree(N):
-    """the two kernels implement the same algorithm: same statuses and costs to 1e-9 relative, iteration counts within rounding effects"""
+    """the compile-time-horizon kernels (one wave per problem for N <= 28, one four-wave workgroup per problem at N = 50) and the generic
+    kernel implement the same algorithm: same statuses and costs to 1e-7 relative, iteration counts within rounding effects"""
     d = make_batch(256, N, cfg_id=6)
     a = _solve(N, d, kernel_variant=0)
     b = _solve(N, d, kernel_variant=1)
