@@ -55,7 +55,7 @@ def certify_one(O, p, z0, ref, v_target, u_prev, U, relax=1e-8):
         cands = [np.zeros(m)]
         if act.any():
             cands[0][act] = _nnls(A[act].T, -g)
-            pr = (cands[0] * slack)[act & (cands[0] > 0)]
+            pr = (cands[0] * slack)[act & (cands[0] > 0) & (slack > 0)]   # (a rounded fp32 iterate may sit a hair outside a relaxed bound)
             if len(pr) and (~act).any() and slack[~act].min() > 0:
                 lam = np.zeros(m)
                 lam[~act] = np.median(pr) / slack[~act]
