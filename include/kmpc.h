@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KMPC_ABI_VERSION 4
+#define KMPC_ABI_VERSION 5
 
 /* per-problem status, replaces the Symbol returned by solve_model() (MKZMPCPathFollower.jl:176,182) */
 enum {
@@ -148,6 +148,15 @@ const char *kmpc_last_error(kmpc_handle *h);
 int32_t kmpc_debug_condense(kmpc_handle *h, int32_t B, const void *z0, const void *ref,
                             const void *v_target, const void *U, int32_t hessian, void *H, void *g,
                             void *J, void *stream);
+/* The KKT pipeline of the kernel kmpc_solve_batch runs for this handle's horizon (compile-time-horizon kernels only: N = 8, 12, ..., 28
+ * one wave per problem; N = 50 fp64 four waves): at inputs U [B,N,2], two-sided form weights w [B,5N-2] (>= 0; order: 2N input boxes,
+ * 2(N-1) rate forms, N speed forms), objective scaling sc > 0 and shift reg >= 0 it assembles
+ *     K = sc * H(U) + A^T diag(w) A + reg * I      (H: exact condensed Hessian if hessian = 1, Gauss-Newton if 0)
+ * on the matrix cores, factors it (blocked Cholesky) and solves once through the block substitutions:
+ *     K_out [B,2N,2N] full symmetric, g [B,2N] = grad J(U), x [B,2N] = K^-1 (b - sc*g), ok [B] int32 (0: K not positive definite) */
+int32_t kmpc_debug_kkt(kmpc_handle *h, int32_t B, const void *z0, const void *ref, const void *v_target, const void *u_prev,
+                       const void *U, const void *w, const void *b, double sc, double reg, int32_t hessian, void *K_out, void *g,
+                       void *x, int32_t *ok, void *stream);
 /* raw v_mfma_{f64,f32}_16x16x4 probe: a[64], b[64] lane operands -> d[64*4] lane-major results */
 int32_t kmpc_debug_mfma_probe(kmpc_handle *h, const void *a, const void *b, void *d, void *stream);
 

@@ -29,7 +29,7 @@ EXPORTS = ["kmpc_abi_version", "kmpc_config_default", "kmpc_create", "kmpc_destr
            "kmpc_get_cost", "kmpc_solve_batch", "kmpc_solve_batch_host", "kmpc_last_error",
            "kmpc_debug_condense", "kmpc_debug_mfma_probe",
            "kmpc_path_create", "kmpc_path_destroy", "kmpc_waypoints_batch", "kmpc_path_last_error",
-           "kmpc_sim_advance_batch", "kmpc_solve_batch_frenet"]
+           "kmpc_sim_advance_batch", "kmpc_solve_batch_frenet", "kmpc_debug_kkt"]
 
 _lib = None
 
@@ -58,6 +58,7 @@ def load():
     L.kmpc_last_error.restype = C.c_char_p
     L.kmpc_debug_condense.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     L.kmpc_debug_mfma_probe.argtypes = [vp, vp, vp, vp, vp]
+    L.kmpc_debug_kkt.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, i32, vp, vp, vp, vp, vp]
     dp = C.POINTER(C.c_double)
     L.kmpc_path_create.argtypes = [i32, i32, dp, dp, dp, dp, dp, C.POINTER(vp)]
     L.kmpc_path_destroy.argtypes = [vp]

@@ -20,6 +20,8 @@ template <typename T> hipError_t kmpc_launch_solve_fast(const KP &, const KIO<T>
 template <typename T> bool kmpc_wide_available(int N);
 template <typename T> hipError_t kmpc_launch_solve_wide(const KP &, const KIO<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_solve_frenet(const KP &, const KIO<T> &, hipStream_t);
+template <typename T> hipError_t kmpc_launch_fast_kkt(const KP &, const KDbgK<T> &, hipStream_t);
+template <typename T> hipError_t kmpc_launch_wide_kkt(const KP &, const KDbgK<T> &, hipStream_t);
 hipError_t kmpc_launch_sim(int, double *, const double *, int, hipStream_t);
 template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, const T *, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
 
@@ -331,6 +333,32 @@ extern "C" int32_t kmpc_debug_condense(kmpc_handle *h, int32_t B, const void *z0
         HIPCHK(h, kmpc_launch_condense<float>(P, io, st));
     }
     return KMPC_OK;
+}
+
+template <typename T>
+static int debug_kkt(kmpc_handle *h, int B, const void *z0, const void *ref, const void *vt, const void *up, const void *U, const void *w,
+                     const void *b, double sc, double reg, int hessian, void *K, void *g, void *x, int32_t *ok, hipStream_t st)
+{
+    const KP P = make_kp(h, B, 0, hessian);
+    KDbgK<T> io = {(const T *)z0, (const T *)ref, (const T *)vt, (const T *)up, (const T *)U, (const T *)w, (const T *)b, sc, reg,
+                   (T *)K, (T *)g, (T *)x, ok};
+    if (kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_fast_kkt<T>(P, io, st));
+    else if (kmpc_wide_available<T>(P.N)) HIPCHK(h, kmpc_launch_wide_kkt<T>(P, io, st));
+    else return fail(h, KMPC_ERR_ARG, "kmpc_debug_kkt: no compile-time-horizon kernel for N=%d in this element type", P.N);
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_debug_kkt(kmpc_handle *h, int32_t B, const void *z0, const void *ref, const void *v_target, const void *u_prev,
+                                  const void *U, const void *w, const void *b, double sc, double reg, int32_t hessian, void *K_out,
+                                  void *g, void *x, int32_t *ok, void *stream)
+{
+    if (!h || B <= 0 || !z0 || !ref || !v_target || !u_prev || !U || !w || !b || !K_out || !g || !x || !ok || !(sc > 0) || !(reg >= 0))
+        return h ? fail(h, KMPC_ERR_ARG, "kmpc_debug_kkt: bad argument") : KMPC_ERR_ARG;
+    if (h->cfg.model != 0) return fail(h, KMPC_ERR_ARG, "kmpc_debug_kkt: Cartesian model only");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->cfg.dtype == KMPC_F64) return debug_kkt<double>(h, B, z0, ref, v_target, u_prev, U, w, b, sc, reg, hessian, K_out, g, x, ok, st);
+    return debug_kkt<float>(h, B, z0, ref, v_target, u_prev, U, w, b, sc, reg, hessian, K_out, g, x, ok, st);
 }
 
 extern "C" int32_t kmpc_debug_mfma_probe(kmpc_handle *h, const void *a, const void *b, void *d, void *stream)

@@ -36,6 +36,15 @@ struct KDbg {
     T *H, *g, *J;
 };
 
+// diagnostics of the KKT pipeline of the compile-time-horizon kernels (kmpc_debug_kkt)
+template <typename T>
+struct KDbgK {
+    const T *z0, *ref, *vt, *up, *U, *w, *b;
+    double sc, reg;
+    T *K, *g, *x;
+    int32_t *ok;
+};
+
 constexpr int KMPC_STG = 36;  // scalars stored per stage in LDS (Cartesian: 13; Frenet: 13 Jacobian + 3 roll-out + 4 costate + 15 Hessian)
 
 // LDS bytes the solver kernel needs for horizon N with NT column tiles

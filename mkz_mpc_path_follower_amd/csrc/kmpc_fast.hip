@@ -1041,6 +1041,70 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void km
     sv.solve(io, b);
 }
 
+// diagnostics (tests/test_gpu_kernels.py): the KKT pipeline of THIS kernel -- roll-out, costates, MFMA condensing, in-register KKT
+// assembly, blocked Cholesky, block substitutions -- at a given point, form weights, scaling and shift
+template <typename T, int N>
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void kmpc_fast_kkt_kernel(KP P, KDbgK<T> io)
+{
+    typedef FastSolver<T, N> SV;
+    typedef typename SV::acc_t acc_t;
+    constexpr int n = SV::n, nf = SV::nf;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SV::lds_elems() * sizeof(T)];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= P.B) return;
+    SV sv(P, smem);
+    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
+    const T sc = (T)io.sc, reg = (T)io.reg;
+    const T U = lane < n ? io.U[(size_t)b * n + lane] : (T)0;
+    StageF<T> St;
+    sv.eval(U, St);
+    const T g = sv.linearize(St, P.hessian == 1);
+    sv.gb[lane] = g;
+    T w[SV::NF];
+#pragma unroll
+    for (int i = 0; i < SV::NF; ++i) { const int f = lane + 64 * i; w[i] = f < nf ? io.w[(size_t)b * nf + f] : (T)0; }
+    sv.stage_form_weights(w);
+    acc_t kt[SV::NTTF];
+    acc_t (&acc)[SV::NTT] = reinterpret_cast<acc_t (&)[SV::NTT]>(kt);
+    sv.condense(sc, acc);
+    sv.build_tiles(sc, reg, kt);
+    T *K = io.K + (size_t)b * n * n;
+#pragma unroll
+    for (int ti = 0; ti < SV::NTF; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + Real<T>::row_of(lane, r), col = 16 * tj + (lane & 15);
+                if (row < n && col <= row) { K[row * n + col] = kt[ti * (ti + 1) / 2 + tj][r]; K[col * n + row] = kt[ti * (ti + 1) / 2 + tj][r]; }
+            }
+    const bool okf = sv.factor(kt);
+    T x = (T)0;
+    if (okf) x = sv.back_subst((lane < n ? sv.Lc[SV::offc_rt(lane) + n] : (T)0) + sv.diag_solve(sv.fwd_subst(lane < n ? io.b[(size_t)b * n + lane] : (T)0)));
+    if (lane < n) { io.g[(size_t)b * n + lane] = g; io.x[(size_t)b * n + lane] = x; }
+    if (lane == 0) io.ok[b] = okf ? 1 : 0;
+}
+template <typename T, int N>
+static hipError_t launch_fast_kkt_n(const KP &P, const KDbgK<T> &io, hipStream_t st)
+{
+    hipLaunchKernelGGL((kmpc_fast_kkt_kernel<T, N>), dim3(P.B), dim3(64), 0, st, P, io);
+    return hipGetLastError();
+}
+template <typename T> hipError_t kmpc_launch_fast_kkt(const KP &P, const KDbgK<T> &io, hipStream_t st)
+{
+    switch (P.N) {
+        case 8: return launch_fast_kkt_n<T, 8>(P, io, st);
+        case 12: return launch_fast_kkt_n<T, 12>(P, io, st);
+        case 16: return launch_fast_kkt_n<T, 16>(P, io, st);
+        case 20: return launch_fast_kkt_n<T, 20>(P, io, st);
+        case 24: return launch_fast_kkt_n<T, 24>(P, io, st);
+        case 28: return launch_fast_kkt_n<T, 28>(P, io, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template hipError_t kmpc_launch_fast_kkt<double>(const KP &, const KDbgK<double> &, hipStream_t);
+template hipError_t kmpc_launch_fast_kkt<float>(const KP &, const KDbgK<float> &, hipStream_t);
+
 template <typename T, int N>
 static hipError_t launch_fast_n(const KP &P, const KIO<T> &io, hipStream_t st)
 {

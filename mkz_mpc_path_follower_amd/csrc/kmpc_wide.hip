@@ -547,7 +547,7 @@ template <typename T, int N> struct WideSolver {
     }
 
     // condense + (max |sc H_jj|) + KKT assembly + factorisation for the tile rows of wave W
-    template <int W> DEV bool assemble_factor(T sc, T reg, bool want_hmax, T &hmax)
+    template <int W> DEV bool assemble_factor(T sc, T reg, bool want_hmax, T &hmax, T *Kdump = nullptr)
     {
         constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
         acc_t k0[Rows<W>::N0], k1[Rows<W>::N1];
@@ -567,6 +567,22 @@ template <typename T, int N> struct WideSolver {
         }
         build_tiles<W>(sc, reg, k0, k1);
         STAMP(4);
+        if (Kdump) {  // diagnostics only (kmpc_debug_kkt): the assembled matrix, full symmetric n x n
+#pragma unroll
+            for (int tj = 0; tj <= R0; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * R0 + Real<T>::row_of(lane, r), col = 16 * tj + (lane & 15);
+                    if (row < n && col <= row) { Kdump[row * n + col] = k0[tj][r]; Kdump[col * n + row] = k0[tj][r]; }
+                }
+#pragma unroll
+            for (int tj = 0; tj <= R1; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * R1 + Real<T>::row_of(lane, r), col = 16 * tj + (lane & 15);
+                    if (col <= row) { Kdump[row * n + col] = k1[R1 >= 0 ? tj : 0][r]; Kdump[col * n + row] = k1[R1 >= 0 ? tj : 0][r]; }
+                }
+        }
         return factor<W>(k0, k1);
     }
 
@@ -997,6 +1013,50 @@ __global__ __launch_bounds__(256, 2) void kmpc_solve_wide_kernel(KP P, KIO<T> io
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
     sv.solve(io, b);
 }
+
+// diagnostics (tests/test_gpu_kernels.py): the KKT pipeline of this kernel at a given point, form weights, scaling and shift
+template <typename T, int N>
+__global__ __launch_bounds__(256, 2) void kmpc_wide_kkt_kernel(KP P, KDbgK<T> io)
+{
+    typedef WideSolver<T, N> SV;
+    constexpr int n = SV::n, nf = SV::nf;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SV::lds_elems() * sizeof(T)];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= P.B) return;
+    SV sv(P, smem);
+    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
+    const T sc = (T)io.sc, reg = (T)io.reg;
+    const T U = tid < n ? io.U[(size_t)b * n + tid] : (T)0;
+    StageW<T> St;
+    sv.eval(U, St);
+    const T g = sv.linearize(St, P.hessian == 1);
+    sv.stage_form_weights(tid < nf ? io.w[(size_t)b * nf + tid] : (T)0);
+    T hm = 0;
+    T *K = io.K + (size_t)b * n * n;
+    bool okf;
+    switch (sv.wv) {
+        case 0: okf = sv.template assemble_factor<0>(sc, reg, false, hm, K); break;
+        case 1: okf = sv.template assemble_factor<1>(sc, reg, false, hm, K); break;
+        case 2: okf = sv.template assemble_factor<2>(sc, reg, false, hm, K); break;
+        default: okf = sv.template assemble_factor<3>(sc, reg, false, hm, K); break;
+    }
+    T x = (T)0;
+    if (okf) x = sv.solve_dir(tid < n ? io.b[(size_t)b * n + tid] : (T)0, true);
+    if (tid < n) { io.g[(size_t)b * n + tid] = g; io.x[(size_t)b * n + tid] = x; }
+    if (tid == 0) io.ok[b] = okf ? 1 : 0;
+}
+template <typename T> hipError_t kmpc_launch_wide_kkt(const KP &P, const KDbgK<T> &io, hipStream_t st)
+{
+    if constexpr (sizeof(T) == 8) {
+        if (P.N == 50) {
+            hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
+            return hipGetLastError();
+        }
+    }
+    return hipErrorInvalidValue;
+}
+template hipError_t kmpc_launch_wide_kkt<double>(const KP &, const KDbgK<double> &, hipStream_t);
+template hipError_t kmpc_launch_wide_kkt<float>(const KP &, const KDbgK<float> &, hipStream_t);
 
 template <typename T> bool kmpc_wide_available(int N) { return sizeof(T) == 8 && N == 50; }
 template <typename T> hipError_t kmpc_launch_solve_wide(const KP &P, const KIO<T> &io, hipStream_t st)

@@ -128,6 +128,26 @@ class BatchMPC:
                                                 int(hessian), _ptr(H), _ptr(g), _ptr(J), stream), self.h)
         return H, g, J
 
+    def debug_kkt(self, z0, ref, v_target, u_prev, U, w, b, sc=1.0, reg=0.0, hessian=1):
+        """kmpc_debug_kkt: K = sc*H(U) + A^T diag(w) A + reg*I as the solve kernel assembles it, gradient, K^-1 (b - sc*g), PD flag"""
+        N = self.N
+        z0 = self._dev(z0, (len(z0), 4))
+        B = z0.shape[0]
+        ref = self._dev(ref, (B, N + 1, 3))
+        v_target = self._dev(v_target, (B,))
+        u_prev = self._dev(u_prev, (B, 2))
+        U = self._dev(U, (B, N, 2))
+        w = self._dev(w, (B, 5 * N - 2))
+        b = self._dev(b, (B, 2 * N))
+        K = torch.zeros((B, 2 * N, 2 * N), dtype=self.dtype, device=self.device)
+        g = torch.zeros((B, 2 * N), dtype=self.dtype, device=self.device)
+        x = torch.zeros((B, 2 * N), dtype=self.dtype, device=self.device)
+        ok = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib.kmpc_debug_kkt(self.h, B, _ptr(z0), _ptr(ref), _ptr(v_target), _ptr(u_prev), _ptr(U), _ptr(w), _ptr(b),
+                                           float(sc), float(reg), int(hessian), _ptr(K), _ptr(g), _ptr(x), _ptr(ok), stream), self.h)
+        return K, g, x, ok
+
     def debug_mfma_probe(self, a, b):
         a = self._dev(a, (64,))
         b = self._dev(b, (64,))
