@@ -784,6 +784,10 @@ template <typename T, int N> struct WideSolver {
         STAMP(0);
 #pragma nounroll
         for (;;) {
+            // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the index / mask / address arithmetic of
+            // every phase out of the loop into registers that then live (and spill) across the whole solve
+            asm volatile("" : "+v"(tid));
+            lane = tid & 63;
             if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && cs[C_ERR] <= pt[PT_TOL])) {
                 Ut = ubl[tid & 127]; U = Ut; status = 0;
             }
@@ -1004,7 +1008,7 @@ template <typename T, int N> struct WideSolver {
 
 // two workgroups (8 waves) per CU: 256 VGPRs per lane
 template <typename T, int N>
-__global__ __launch_bounds__(256, 2) void kmpc_solve_wide_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? 2 : 4) void kmpc_solve_wide_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WideSolver<T, N>::lds_elems() * sizeof(T)];
     if ((int)blockIdx.x >= P.B) return;
@@ -1047,25 +1051,21 @@ __global__ __launch_bounds__(256, 2) void kmpc_wide_kkt_kernel(KP P, KDbgK<T> io
 }
 template <typename T> hipError_t kmpc_launch_wide_kkt(const KP &P, const KDbgK<T> &io, hipStream_t st)
 {
-    if constexpr (sizeof(T) == 8) {
-        if (P.N == 50) {
-            hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
-            return hipGetLastError();
-        }
+    if (P.N == 50) {
+        hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
+        return hipGetLastError();
     }
     return hipErrorInvalidValue;
 }
 template hipError_t kmpc_launch_wide_kkt<double>(const KP &, const KDbgK<double> &, hipStream_t);
 template hipError_t kmpc_launch_wide_kkt<float>(const KP &, const KDbgK<float> &, hipStream_t);
 
-template <typename T> bool kmpc_wide_available(int N) { return sizeof(T) == 8 && N == 50; }
+template <typename T> bool kmpc_wide_available(int N) { return N == 50; }
 template <typename T> hipError_t kmpc_launch_solve_wide(const KP &P, const KIO<T> &io, hipStream_t st)
 {
-    if constexpr (sizeof(T) == 8) {
-        if (P.N == 50) {
-            hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
-            return hipGetLastError();
-        }
+    if (P.N == 50) {
+        hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
+        return hipGetLastError();
     }
     return hipErrorInvalidValue;
 }

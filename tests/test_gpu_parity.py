@@ -74,10 +74,23 @@ def test_batch_fp32(oracle):
     r = _solve(N, d, dtype=torch.float32)
     p = O.params(N)
     ro = O.solve_condensed_batch(p, d["z0"], d["ref"], d["v_target"], d["u_prev"], nthreads=8)
-    ok = r["status"] == 0
-    assert ok.mean() > 0.95, np.bincount(r["status"])
+    assert (r["status"] == 0).all(), np.bincount(r["status"])   # (every problem of the 262 144-problem config-3 batch is Optimal: tests/test_certify.py)
     rel = np.abs(r["cost"] - ro["cost"]) / np.maximum(1.0, np.abs(ro["cost"]))
-    assert rel[ok].max() <= 1e-3, rel[ok].max()
+    assert rel.max() <= 1e-3, rel.max()
+    assert r["viol"].max() <= 1e-4
+
+
+def test_batch_fp32_long_horizon(oracle):
+    """N = 50 in fp32 (four-wave kernel, 4 workgroups per CU): all Optimal and feasible; cost within the fp32 tolerance (1e-3 relative) of
+    the fp64 oracle on >= 98 % of the draw and within 2e-2 on all of it (sums of ~50 squared residuals of 1e2 ... 1e3 m^2 in fp32)"""
+    O = oracle
+    N, B = 50, 192
+    d = make_batch(B, N, cfg_id=5)
+    r = _solve(N, d, dtype=torch.float32)
+    ro = O.solve_condensed_batch(O.params(N), d["z0"], d["ref"], d["v_target"], d["u_prev"], nthreads=8)
+    assert (r["status"] == 0).all(), np.bincount(r["status"])
+    rel = np.abs(r["cost"] - ro["cost"]) / np.maximum(1.0, np.abs(ro["cost"]))
+    assert (rel <= 1e-3).mean() >= 0.98 and rel.max() <= 2e-2, (np.sort(rel)[-5:], (rel > 1e-3).sum())
     assert r["viol"].max() <= 1e-4
 
 
