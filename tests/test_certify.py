@@ -63,7 +63,9 @@ def test_certifier_accepts_kkt_points_and_rejects_others(oracle, N, B):
 def test_zero_start_fixture_is_what_the_oracle_computes(oracle, N):
     """tests/golden/kmpc_zero_start_N*.npz (oracle/make_zero_start.py): the condensed oracle reproduces its stored answers, the stored
     full-space zero-start answers (Q9, MKZMPCPathFollower.jl:65-72) are Optimal, and the number of problems on which the two
-    end in different local minima is what the fixture says (N=8: 0, N=20: 1, N=50: see DESIGN.md section 6)"""
+    end in different local minima is what the fixture says: N = 8: 0 of 208, N = 20: 1, N = 50: 11 -- in every one of those the feed-forward
+    start of the kernels' algorithm reaches the LOWER minimum (a 10 s horizon from an all-zero input guess leaves Ipopt's iterates in the
+    basin of a worse stationary point more often than a 1.6 s or 4 s horizon does)"""
     O = oracle
     G = np.load(os.path.join(GOLD, "kmpc_zero_start_N%d.npz" % N))
     assert len(G["J_ipopt_like"]) >= 200 and G["hard"].sum() >= 1
@@ -74,7 +76,8 @@ def test_zero_start_fixture_is_what_the_oracle_computes(oracle, N):
     assert np.abs(r["cost"] - G["J_condensed"][S]).max() <= 1e-9 * np.abs(G["J_condensed"][S]).max()
     rel = np.abs(G["J_condensed"] - G["J_ipopt_like"]) / np.maximum(1.0, np.abs(G["J_ipopt_like"]))
     other = rel > 1e-6
-    assert other.mean() <= 0.02, other.sum()
+    assert int(other.sum()) == {8: 0, 20: 1, 50: 11}[N]
+    assert (G["J_condensed"][other] < G["J_ipopt_like"][other]).all()
     # where they differ, both are certified KKT points (different local minima of a non-convex program, not a solver failure)
     d = dict(z0=G["z0"], ref=G["ref"], v_target=G["v_target"], u_prev=G["u_prev"])
     for U in (G["U_condensed"], G["U_ipopt_like"]):
@@ -153,7 +156,8 @@ def test_gpu_minimum_vs_reference_zero_start(oracle, N):
     other = rel > 1e-6
     print("N=%d: %d of %d problems end in a local minimum other than the zero-start one (GPU lower in %d); max rel cost gap %.2e"
           % (N, other.sum(), len(Jz), (other & (r["cost"] < Jz)).sum(), rel.max()))
-    assert other.mean() <= 0.02
+    assert other.mean() <= (0.02 if N < 50 else 0.08)              # N = 8: 0, N = 20: 1, N = 50: 11 of 208 (fixture)
+    assert (r["cost"][other] < Jz[other]).all()                    # ... and there the kernel's minimum is the lower one
     assert np.abs(r["u0"] - G["U_ipopt_like"][:, 0, :])[~other].max() <= 1e-4
     if other.any():
         _assert_certified(CT.certify_batch(oracle, oracle.params(N, G["weights"]), d, r["U"], idx=np.where(other)[0]), 1e-6 if N < 50 else 1e-5, 1e-8 + 1e-12, "N=%d" % N)
