@@ -1,7 +1,7 @@
 """Turn the rocprofv3 (rocpd sqlite) output of tools/profile_round.sh into the committed summaries under profiles/:
    <tag>_kernel_stats.csv  per (kernel, grid) calls / average / min / max duration from --kernel-trace
    <tag>_bench.json        the bench line of the same command without the profiler
-   r1_pmc_traffic.json     FETCH_SIZE / WRITE_SIZE per dispatch of the B=4096 solve kernel (separate --pmc passes)
+   <round>_pmc_traffic.json FETCH_SIZE / WRITE_SIZE per dispatch of the B=4096 solve kernel (separate --pmc passes)
 Usage: python tools/profile_digest.py r1_v5 "note about the build" """
 import csv, glob, json, os, shutil, sqlite3, sys
 
@@ -24,6 +24,15 @@ with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"), "w", newlin
     for r in rows:
         w.writerow(r)
 shutil.copy(os.path.join(src, "bench_plain.json"), os.path.join(ROOT, "profiles", tag + "_bench.json"))
+if glob.glob(os.path.join(src, "trace_full", "*_results.db")):   # the full default bench: multi-seed batches and the other BASELINE configs
+    rows_all = db("trace_full").execute(
+        "select name, grid_x, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(scratch_size), max(lds_size) "
+        "from kernels where name like '%kmpc_%' group by name, grid_x order by sum(duration) desc").fetchall()
+    with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats_all_configs.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "GridX", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "VGPRs", "ScratchBytesPerLane", "LDSBytes"])
+        for r in rows_all:
+            w.writerow(r)
 
 out = {}
 for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -39,11 +48,20 @@ out["hbm_bytes_per_dispatch_uncorrected"] = 1024.0 * (out["FETCH_SIZE_KB_per_dis
 out["hbm_bytes_per_dispatch"] = 1024.0 * (2 * out["FETCH_SIZE_KB_per_dispatch"] + out["WRITE_SIZE_KB_per_dispatch"])
 if note:
     out["build"] = note
-pj = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-j = json.load(open(pj))
+rnd = tag.split("_")[0]   # r1 / r2 ...: one traffic file per round
+pj = os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")
+if os.path.exists(pj):
+    j = json.load(open(pj))
+else:  # a new round starts from the calibration note of the previous one
+    prev = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+    j = {k: v for k, v in prev.items() if k not in ("runs", "current")}
+    j["runs"] = {}
 j["runs"][tag] = out
 j["current"] = tag
 json.dump(j, open(pj, "w"), indent=1)
+st = glob.glob(os.path.join(src, "trace_csv", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    shutil.copy(st[0], os.path.join(ROOT, "profiles", tag + "_rocprofv3_kernel_stats.csv"))
 for r in rows[:6]:
     print(r)
 print(json.dumps(out, indent=1))

@@ -2,10 +2,10 @@
 # SQ counter passes (<= 8 SQ slots each) of the short bench; digests into gpurun_out/sq_<tag>/sq_counters.json
 set -eo pipefail
 export TMPDIR=/tmp
-TAG=${1:-r1_v8}
+TAG=${1:-r2_v1}
 OUT=gpurun_out/sq_$TAG; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -d $OUT/a -o a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/a.err
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 -d $OUT/b -o b -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/b.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -d $OUT/a -o a -- python3 bench.py --quick --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/a.err
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 -d $OUT/b -o b -- python3 bench.py --quick --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/b.err
 python3 - "$TAG" <<'PY'
 import sqlite3, glob, json, sys
 tag = sys.argv[1]
