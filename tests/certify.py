@@ -38,7 +38,11 @@ def _nnls(M, rhs):
 
 
 def certify_one(O, p, z0, ref, v_target, u_prev, U, relax=1e-8):
-    q = O.problem(p, z0, ref, v_target, u_prev)
+    return certify_problem(O, p, O.problem(p, z0, ref, v_target, u_prev), U, relax)
+
+
+def certify_problem(O, p, q, U, relax=1e-8):
+    """q: an oracle problem object (O.problem for the Cartesian model, O.problem_frenet for the Frenet functor)"""
     U = np.asarray(U, dtype=np.float64).reshape(-1)
     A, b = O.ineq(p, q, relax=relax)
     g = O.grad(p, q, U)

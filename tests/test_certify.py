@@ -96,10 +96,12 @@ def _gpu_solve(N, d, dtype, **kw):
 
 
 @pytest.mark.gpu
-def test_certify_config2_B4096_N20_fp64(oracle):
-    """BASELINE configs[1]: every one of the 4096 returned U of the bench batch is a certified KKT point"""
+@pytest.mark.parametrize("N", [20, 8])
+def test_certify_config2_B4096_N20_fp64(oracle, N):
+    """BASELINE configs[1] (N = 20; and the same batch size at the reference's own horizon N = 8, configs[0]'s model): every one of the
+    4096 returned U of the bench batch is a certified KKT point"""
     import torch
-    N, B = 20, 4096
+    B = 4096
     d = make_batch(B, N, cfg_id=2)
     r = _gpu_solve(N, d, torch.float64)
     assert (r["status"] == 0).all(), np.bincount(r["status"])
@@ -161,3 +163,27 @@ def test_gpu_minimum_vs_reference_zero_start(oracle, N):
     assert np.abs(r["u0"] - G["U_ipopt_like"][:, 0, :])[~other].max() <= 1e-4
     if other.any():
         _assert_certified(CT.certify_batch(oracle, oracle.params(N, G["weights"]), d, r["U"], idx=np.where(other)[0]), 1e-6 if N < 50 else 1e-5, 1e-8 + 1e-12, "N=%d" % N)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,B", [(8, 1024), (20, 512)])
+def test_certify_frenet_functor(oracle, N, B):
+    """SURVEY.md 8(f3), MKZMPCPathFollowerFrenet.jl:64-123: the returned inputs of the Frenet-frame functor are certified KKT points of
+    THAT model's NLP (same inequality rows; gradient by the oracle's model switch), at the fp64 tolerances above"""
+    import torch
+    from test_frenet import _cases
+    from mkz_mpc_path_follower_amd import BatchMPC
+    O = oracle
+    z0, kp, vt, up = _cases(B, N, seed=33)
+    s = BatchMPC(N=N, dtype=torch.float64, model=1)
+    o = s.solve_frenet(z0, kp, vt, up, want_U=True)
+    torch.cuda.synchronize()
+    U, st = o["U"].cpu().numpy(), o["status"].cpu().numpy()
+    assert (st == 0).all(), np.bincount(st)
+    p = O.params(N, model=1)
+    out = {k: [] for k in CT.KEYS}
+    for b in range(B):
+        c = CT.certify_problem(O, p, O.problem_frenet(p, z0[b], kp[b], vt[b], up[b]), U[b])
+        for k in CT.KEYS:
+            out[k].append(c[k])
+    _assert_certified({k: np.array(v) for k, v in out.items()}, 1e-6, 1e-8 + 1e-12, "Frenet N=%d" % N)
