@@ -30,6 +30,8 @@ def test_bench_line_single_gpu():
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] and rf["kernel_ms"] <= d["ms_per_step"] * 1.02
     ms = d["multi_seed"]
     assert ms["seeds"] >= 8 and ms["min"] <= ms["mean"] <= ms["max"] and ms["all_optimal"]
+    tb = d["two_batches_in_flight"]
+    assert tb["batches_in_flight"] == 2 and tb["all_optimal"] and tb["solves_per_s"] > d["value"]   # the next batch fills the tail
     for key, kern_peak in (("config3_fp32_B262144", 157.3), ("config5_N50_B4096", 78.6), ("config4_shard_fp64_B262144", 78.6)):
         c = d[key]
         assert c["optimal_fraction"] == 1.0 and c["peak_tflops"] == kern_peak and 0 < c["frac_of_peak"] < 1 and c["solves_per_s"] > 0
