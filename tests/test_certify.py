@@ -187,3 +187,36 @@ def test_certify_frenet_functor(oracle, N, B):
         for k in CT.KEYS:
             out[k].append(c[k])
     _assert_certified({k: np.array(v) for k, v in out.items()}, 1e-6, 1e-8 + 1e-12, "Frenet N=%d" % N)
+
+
+@pytest.mark.gpu
+def test_certify_closed_loop_warm_started_solves(oracle):
+    """The drop-in use itself (mpc_cmd_pub.jl:86-157 for a fleet): N = 8, 10 Hz, warm-started from the previous solution, rate limits
+    anchored to the last command, waypoints from the recorded path.  Every solve of selected control periods is a certified KKT
+    point of that period's NLP (cold first solve, early transient from rest, steady tracking)."""
+    import torch
+    from mkz_mpc_path_follower_amd.ref_traj import GPSRefTrajectory
+    from mkz_mpc_path_follower_amd.vehicle_sim import VehicleSimulator
+    from mkz_mpc_path_follower_amd.closed_loop import ClosedLoop
+    d = np.load(os.path.join(GOLD, "path1_decimated.npz"))
+    N, B, vt = 8, 256, 8.0
+    grt = GPSRefTrajectory(arrays=dict(t=d["t"], lat=d["lat"], lon=d["lon"], psi=d["psi"]), traj_horizon=N, traj_dt=0.2)
+    tr = grt.get_global_trajectory_reference()
+    rng = np.random.default_rng(17)
+    idx = rng.integers(0, int(0.6 * len(tr)), B)
+    lat = rng.normal(0, 0.5, B)
+    sim = VehicleSimulator(B, X0=tr[idx, 4] - lat * np.sin(tr[idx, 3]), Y0=tr[idx, 5] + lat * np.cos(tr[idx, 3]), Psi0=tr[idx, 3] + rng.normal(0, 0.05, B))
+    loop = ClosedLoop(grt, sim, N=N, target_vel=vt)
+    O = oracle
+    p = O.params(N)
+    for k in range(60):
+        z0 = sim.state[:, 0:4].cpu().numpy().copy()
+        up = loop.u_prev.cpu().numpy().copy()
+        o = loop.step()
+        if k in (0, 1, 5, 20, 59):
+            torch.cuda.synchronize()
+            assert (o["status"] == 0).all()
+            dd = dict(z0=z0, ref=o["ref"].cpu().numpy(), v_target=np.full(B, vt), u_prev=up)
+            c = CT.certify_batch(O, p, dd, loop.warm_U.cpu().numpy())      # warm_U holds the solution of the period just solved
+            _assert_certified(c, 1e-6, 1e-8 + 1e-12, "closed loop, period %d" % k)
+            assert np.abs(c["cost"] - o["cost"].cpu().numpy()).max() <= 1e-9 * max(1.0, np.abs(c["cost"]).max())

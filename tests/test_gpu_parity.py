@@ -133,6 +133,30 @@ def test_full_size_batch_properties():
     assert np.allclose(X[:, 1:, 3], X[:, :-1, 3] + 0.2 * U[:, :, 0], atol=1e-12)
 
 
+def test_long_horizon_batch_properties():
+    """BASELINE configs[4] at full size (B = 4096, N = 50; four-wave kernel): every problem Optimal and feasible; the mirrored batch has the
+    same optimal costs, the same accelerations and negated steering; the returned states are the roll-out of the returned inputs; the
+    start order (active above 2048 problems) does not change a single bit of any output."""
+    N, B = 50, 4096
+    d = make_batch(B, N, cfg_id=5)
+    r = _solve(N, d)
+    assert (r["status"] == 0).all(), np.bincount(r["status"])
+    assert r["viol"].max() <= 1e-8 + 1e-12 and np.isfinite(r["cost"]).all()
+    m = dict(d)
+    m["z0"] = d["z0"] * np.array([1, -1, -1, 1.0])
+    m["ref"] = d["ref"] * np.array([1, -1, -1.0])
+    m["u_prev"] = d["u_prev"] * np.array([1, -1.0])
+    rm = _solve(N, m)
+    rel = np.abs(r["cost"] - rm["cost"]) / np.maximum(1.0, np.abs(r["cost"]))
+    same = rel <= 1e-6
+    assert same.mean() >= 0.995, (rel.max(), (~same).sum())      # (a negative-curvature problem may land in another local minimum)
+    assert np.abs(r["u0"][:, 0] - rm["u0"][:, 0])[same].max() <= 1e-5 and np.abs(r["u0"][:, 1] + rm["u0"][:, 1])[same].max() <= 1e-5
+    assert np.allclose(r["X"][:, 1:, 3], r["X"][:, :-1, 3] + 0.2 * r["U"][:, :, 0], atol=1e-12)
+    a = _solve(N, d, schedule=0)
+    for k in ("status", "iters", "cost", "viol", "u0", "U", "X"):
+        assert np.array_equal(a[k], r[k]), k
+
+
 def test_full_size_rigid_motion_invariance():
     """Size-independent property at BASELINE configs[1] size: with C_x = C_y (the node's weights) the NLP is invariant under a rigid
     motion of the plane -- rotate and translate poses and references by a recorded-path-sized offset and the optimal costs and
