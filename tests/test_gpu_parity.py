@@ -210,7 +210,7 @@ def test_infeasible_and_edge_inputs():
     assert o["u0"].shape == (0, 2)  # empty batch is a no-op
 
 
-@pytest.mark.parametrize("N", [8, 20, 13])
+@pytest.mark.parametrize("N", [8, 20, 13, 50])
 def test_bad_inputs_are_contained(oracle, N):
     """NaN / Inf / out-of-range inputs in some problems of a batch: those problems report Infeasible (2) or Error (3) -- as the oracle
     does -- with finite commands inside the input box (the reference node publishes whatever it gets, mpc_cmd_pub.jl:121-132), and
