@@ -234,10 +234,10 @@ def test_bad_inputs_are_contained(oracle, N):
     assert list(ro["status"]) == [2, 2, 0, 0, 2, 2]
 
 
-def test_warm_start_and_host_entry(oracle):
+@pytest.mark.parametrize("N,B", [(20, 128), (50, 64)])
+def test_warm_start_and_host_entry(oracle, N, B):
     from mkz_mpc_path_follower_amd import BatchMPC
     from mkz_mpc_path_follower_amd.solver import solve_host
-    N, B = 20, 128
     d = make_batch(B, N, cfg_id=4)
     s = BatchMPC(N=N)
     W = torch.zeros((B, N, 2), dtype=torch.float64, device="cuda")
