@@ -81,7 +81,8 @@ typedef struct kmpc_config {
                                Calls on one handle must be stream-ordered (the permutation workspace belongs to the handle). */
     int32_t model;          /* 0 (default) = MKZMPCPathFollower.jl, Cartesian states (x, y, psi, v); 1 = MKZMPCPathFollowerFrenet.jl,
                                Frenet-frame states (s, e_y, e_psi, v) with a cubic curvature polynomial (kmpc_solve_batch_frenet;
-                               horizons N <= 24).  kmpc_create picks the cost defaults of the chosen module. */
+                               horizons N <= 24, and N = 28 with kernel_variant 0: the compile-time-horizon kernels carry the functor
+                               for N = 8, 12, ..., 28).  kmpc_create picks the cost defaults of the chosen module. */
 } kmpc_config;
 
 typedef struct kmpc_handle kmpc_handle;

@@ -20,6 +20,7 @@ template <typename T> hipError_t kmpc_launch_solve_fast(const KP &, const KIO<T>
 template <typename T> bool kmpc_wide_available(int N);
 template <typename T> hipError_t kmpc_launch_solve_wide(const KP &, const KIO<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_solve_frenet(const KP &, const KIO<T> &, hipStream_t);
+template <typename T> hipError_t kmpc_launch_solve_fast_frenet(const KP &, const KIO<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_fast_kkt(const KP &, const KDbgK<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_wide_kkt(const KP &, const KDbgK<T> &, hipStream_t);
 hipError_t kmpc_launch_sim(int, double *, const double *, int, hipStream_t);
@@ -107,7 +108,8 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
         !(cfg->v_max > cfg->v_min) || !(cfg->a_max > 0) || !(cfg->steer_max > 0) || !(cfg->steer_max < 1.5) ||
         !(cfg->a_dmax > 0) || !(cfg->steer_dmax > 0) || cfg->max_iter < 1 || cfg->max_ls < 1 || !(cfg->tol > 0) ||
         cfg->kernel_variant < 0 || cfg->kernel_variant > 1 || cfg->mu_strategy < 0 || cfg->mu_strategy > 1 ||
-        cfg->indef_strategy < 0 || cfg->indef_strategy > 2 || cfg->schedule < 0 || cfg->schedule > 1 || cfg->model < 0 || cfg->model > 1 || (cfg->model == 1 && cfg->N > 24))
+        cfg->indef_strategy < 0 || cfg->indef_strategy > 2 || cfg->schedule < 0 || cfg->schedule > 1 || cfg->model < 0 || cfg->model > 1 ||
+        (cfg->model == 1 && cfg->N > 24 && !(cfg->kernel_variant == 0 && cfg->N == 28)))  // Frenet: generic kernel up to N = 24, compile-time kernel also at 28
         return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: invalid model / solver parameter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_create: no HIP device");
@@ -198,8 +200,9 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
     const KP P = make_kp(h, B, warm && warmU ? 1 : 0, -1);
     io.perm = nullptr;
     // start order: only matters once a launch no longer fits on the chip at once (2 waves x 4 SIMDs x 256 CUs)
-    if (h->cfg.model == 1) {  // Frenet functor: `ref` carries k_poly [B,4]; generic kernel, index order
-        HIPCHK(h, kmpc_launch_solve_frenet<T>(P, io, st));
+    if (h->cfg.model == 1) {  // Frenet functor: `ref` carries k_poly [B,4]; index order (the start-order key reads reference points)
+        if (h->cfg.kernel_variant == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast_frenet<T>(P, io, st));
+        else HIPCHK(h, kmpc_launch_solve_frenet<T>(P, io, st));   // generic kernel: N <= 24
         return KMPC_OK;
     }
     if (h->cfg.schedule == 1 && B > 2048) {

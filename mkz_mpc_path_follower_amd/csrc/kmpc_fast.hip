@@ -31,6 +31,7 @@
 
 template <typename T> struct StageF {  // lane k: state k / input k at the evaluated point
     T a, d, v, x, y, psi, c, s, sinb, cosb, b1, b2, ex, ey, ep, ev;
+    T K, Kp, iden, dsdt;  // Frenet functor only: curvature, dK/ds, 1 / (1 - e_y K), ds/dt at the stage
 };
 // linearisation scalars of stage k, parked in LDS (16 words per stage):
 // A02 A03 A12 A13 A23 Bdx Bdy Bdp mpp mpv mpd mvd mdd 0
@@ -39,7 +40,12 @@ constexpr int LIN_STRIDE = 16;
 #ifndef KMPC_IKRD
 #define KMPC_IKRD 1e-3
 #endif
-template <typename T, int N> struct FastSolver {
+// MODEL 0: Cartesian kinematic bicycle (MKZMPCPathFollower.jl); MODEL 1: Frenet-frame functor (MKZMPCPathFollowerFrenet.jl:112-123): states
+// (s, e_y, e_psi, v) in the (x, y, psi, v) slots, zero cost references, curvature polynomial K(s); only roll-out, costates and the
+// sensitivity recursion differ (the dynamics couple s, e_y, e_psi, so they are serial recursions on wave-uniform values and the stage
+// Jacobians are dense) -- forms, barrier method, MFMA contraction, KKT assembly, factorisation and substitutions are shared.
+template <typename T, int N, int MODEL = 0> struct FastSolver {
+    static constexpr int LSTR = MODEL == 1 ? KMPC_STG : LIN_STRIDE;  // stage record stride (Frenet: 13 Jacobian + 3 roll-out + 4 costate + 15 Hessian)
     static constexpr int n = 2 * N, R = 2 * (N - 1), nf = 5 * N - 2;
     static constexpr int NF = (nf + 63) / 64;
     static constexpr int NT = (n + 15) / 16, NTT = NT * (NT + 1) / 2;
@@ -48,7 +54,7 @@ template <typename T, int N> struct FastSolver {
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
     static_assert(n + 1 <= 64 && n % 8 == 0, "fast kernel needs 2N + 1 <= 64 and N % 4 == 0");
     typedef typename Real<T>::acc_t acc_t;
-    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LIN_STRIDE * (N + 1) + 8 * 64 + 16 + 64 + 64 + 2 * 64 * NF + 16 * (n / 4) + (sizeof(T) == 8 ? KC_COUNT : 0); }
+    static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LSTR * (N + 1) + 8 * 64 + 16 + 64 + 64 + 2 * 64 * NF + 16 * (n / 4) + (sizeof(T) == 8 ? KC_COUNT : 0); }
     // start of column j minus j, so that element (row i, col j) lives at offc(j) + i
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
@@ -60,6 +66,7 @@ template <typename T, int N> struct FastSolver {
     T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *gb, *cub, *clb, *sinvb;
     Coef<T> kc;  // polynomial coefficients (LDS table in fp64)
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
+    T kp0, kp1, kp2, kp3;  // Frenet: K(s) = kp0 s^3 + kp1 s^2 + kp2 s + kp3
     // Kernel-argument scalars (model constants, limits, tolerances, the doubled weights 2*C_i, products like dt^2 that the host
     // computed because there is no scalar fp64 ALU) are copied once into an LDS table, pt = cb + 32 (cb holds N <= 28 suffix sums), and
     // read from there: the kernarg segment arrives as 16-SGPR tuples which the allocator spills and then reloads WHOLE at every use
@@ -76,7 +83,7 @@ template <typename T, int N> struct FastSolver {
         wb = xb + 64;
         cb = wb + 64 * NF;
         lin = cb + 64;
-        opb = lin + LIN_STRIDE * (N + 1);
+        opb = lin + LSTR * (N + 1);
         cs = opb + 8 * 64;      // wave-uniform scalars that are read once or twice per iteration live here, not in VGPRs
         ubest = cs + 16;        // last iterate that passed Ipopt's test
         gb = ubest + 64;        // gradient of the current linearisation (lane j: g_j)
@@ -98,13 +105,28 @@ template <typename T, int N> struct FastSolver {
             q[PT_V_MIN] = (T)p.v_min; q[PT_V_MAX] = (T)p.v_max; q[PT_RELAX] = (T)p.relax; q[PT_WARM_PUSH] = (T)p.warm_push;
             q[PT_WARM_MU] = (T)p.warm_mu; q[PT_MU_INIT] = (T)p.mu_init; q[PT_INV2NF] = (T)(1.0 / (2 * nf));
         }
+        // the tables are written by a few lanes and read by all: order the reads behind the writes (found with poisoned LDS in the
+        // Frenet instantiation, whose first reads of the table were scheduled ahead of lane 0's stores -- invisible whenever the
+        // previous occupant of the LDS was the same kernel, because the constants it left behind are the same)
+        WSYNC();
     }
 
     DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)
     {
+        if (MODEL == 1) {  // `ref` carries k_poly [B,4]; (s, e_y) are not translation-invariant (K depends on s); zero cost references
+            xoff = yoff = (T)0; x0 = z0[4 * (size_t)b]; y0 = z0[4 * (size_t)b + 1];
+            psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
+            vt = vtp[b];
+            up0 = upp[2 * (size_t)b]; up1 = upp[2 * (size_t)b + 1];
+            rx = ry = rp = (T)0;
+            const T *kp = ref + 4 * (size_t)b;
+            kp0 = kp[0]; kp1 = kp[1]; kp2 = kp[2]; kp3 = kp[3];
+            return;
+        }
         // the NLP is invariant under a translation of (x, y): solve it in vehicle-centred coordinates (recorded paths live hundreds
         // of metres from their origin; positions would carry ~1e-13 m of rounding = ~1e-12 in the cost, above the Armijo
         // decrease of the last iterations); predictions are shifted back on output
+        kp0 = kp1 = kp2 = kp3 = (T)0;
         xoff = z0[4 * (size_t)b]; yoff = z0[4 * (size_t)b + 1]; x0 = (T)0; y0 = (T)0;
         psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
         vt = vtp[b];
@@ -189,6 +211,7 @@ template <typename T, int N> struct FastSolver {
     // roll-out (MKZMPCPathFollower.jl:115-122 as prefix scans) + objective (:97-103) at U (lane j: U_j)
     DEV T eval(T U, StageF<T> &S)
     {
+        if constexpr (MODEL == 1) return eval_frenet(U, S);
         const T dt = pt[PT_DT], rr_ = pt[PT_RR], dtL = pt[PT_DTL];
         if (lane < n) xb[lane] = U;
         WSYNC();
@@ -238,6 +261,7 @@ template <typename T, int N> struct FastSolver {
     // costates by suffix scans -> gradient (returned, lane j: g_j); per-stage scalars go to LDS (Lc alias)
     DEV T linearize(const StageF<T> &S, bool exact)
     {
+        if constexpr (MODEL == 1) return linearize_frenet(S, exact);
         const T dt = pt[PT_DT], dtL = pt[PT_DTL];
         const int k = lane;
         const bool st = k < N;
@@ -272,7 +296,7 @@ template <typename T, int N> struct FastSolver {
                   pp1 * (dtL * v * (-S.sinb * b1 * b1 + S.cosb * b2));
         }
         {
-            T *q = lin + LIN_STRIDE * (k <= N ? k : N);
+            T *q = lin + LSTR * (k <= N ? k : N);
             T *dmy = xb + 62;  // lanes > N write past the n <= 56 gradient entries held in xb
             T *w0 = k <= N ? q : dmy;
             w0[0] = A02; w0[1] = A03;
@@ -283,6 +307,218 @@ template <typename T, int N> struct FastSolver {
         const T g = lane < n ? xb[lane] : (T)0;
         WSYNC();
         return g;
+    }
+
+
+    // ================= Frenet functor (MODEL 1), MKZMPCPathFollowerFrenet.jl:112-123 ======================================================
+    // Roll-out: a serial recursion over the stages on wave-uniform values (every lane runs it; lane k keeps stage k).
+    DEV T eval_frenet(T U, StageF<T> &S)
+    {
+        const T dt = pt[PT_DT], rr_ = pt[PT_RR], dtL = pt[PT_DTL];
+        if (lane < n) xb[lane] = U;
+        WSYNC();
+        const int k = lane;
+        const bool st = k < N;
+        const T a = st ? xb[2 * k] : (T)0, d = st ? xb[2 * k + 1] : (T)0;
+        const T an = (k + 1 < N) ? xb[2 * k + 2] : a, dn = (k + 1 < N) ? xb[2 * k + 3] : d;
+        S.a = a; S.d = d;
+        T sd, cd;
+        sincos_small(d, &sd, &cd, kc);
+        const T Dn = cd * cd + rr_ * rr_ * sd * sd;
+        const T rs = rsqrt_(Dn);
+        S.sinb = rr_ * sd * rs;  // sin(atan(r tan d))   (:113)
+        S.cosb = cd * rs;
+        const T iD = rs * rs;
+        S.b1 = rr_ * iD;                                                    // d beta / d d_f
+        S.b2 = rr_ * ((T)1 - rr_ * rr_) * ((T)2 * sd * cd) * (iD * iD);     // d2 beta / d d_f2
+        if (st) { T *q = lin + LSTR * k; q[13] = a; q[14] = S.sinb; q[15] = S.cosb; }  // slots 0..12 hold the stage Jacobians
+        WSYNC();
+        T s_ = x0, ey_ = y0, ep_ = psi0, v_ = v0;
+        S.x = S.y = S.psi = S.v = S.c = S.s = S.K = S.Kp = S.iden = S.dsdt = (T)0;
+#pragma nounroll
+        for (int kk = 0; kk <= N; ++kk) {
+            const T K = ((kp0 * s_ + kp1) * s_ + kp2) * s_ + kp3;               // :112
+            const T Kp = ((T)3 * kp0 * s_ + (T)2 * kp1) * s_ + kp2;
+            if (lane == kk) { S.x = s_; S.y = ey_; S.psi = ep_; S.v = v_; S.K = K; S.Kp = Kp; }
+            if (kk == N) break;
+            const T *q = lin + LSTR * kk;
+            const T ak = q[13], sb = q[14], cbt = q[15];
+            T sp, cp;
+            sincos_mid(ep_, &sp, &cp, kc);
+            const T c = cp * cbt - sp * sb, sn = sp * cbt + cp * sb;            // cos / sin(e_psi + beta)
+            const T iden = rcp_((T)1 - ey_ * K), dsdt = v_ * c * iden;          // :114
+            if (lane == kk) { S.c = c; S.s = sn; S.iden = iden; S.dsdt = dsdt; }
+            s_ += dt * dsdt;                                                     // :118
+            ey_ += dt * (v_ * sn);                                               // :119
+            ep_ += dtL * v_ * sb - dt * dsdt * K;                                // :120
+            v_ += dt * ak;                                                       // :121
+        }
+        WSYNC();
+        const bool cs = (k >= 1 && k <= N);
+        S.ex = cs ? S.x : (T)0;      // zero references (the s weight is 0: Frenet.jl:97-98 has no s term)
+        S.ey = cs ? S.y : (T)0;
+        S.ep = cs ? S.psi : (T)0;
+        S.ev = (k >= 1 && k <= N - 1) ? S.v - vt : (T)0;
+        const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3], Cda2 = cwt[4], Cdd2 = cwt[5], Ca2 = cwt[6], Cd2 = cwt[7];
+        T Jl = Cx2 * S.ex * S.ex + Cy2 * S.ey * S.ey + Cp2 * S.ep * S.ep + Cv2 * S.ev * S.ev;
+        if (st) Jl += Ca2 * a * a + Cd2 * d * d;
+        if (k < N - 1) Jl += Cda2 * (an - a) * (an - a) + Cdd2 * (dn - d) * (dn - d);
+        Jl *= (T)0.5;
+        return dpp_sum(Jl);
+    }
+
+    // stage record of the Frenet functor: A00 A01 A02 A03 A12 A13 A20 A21 A22 A23 Bs Bey Bep  (A11 = A33 = 1, B_v,acc = dt), roll-out
+    // scratch 13..15, costate of the state 16..19, second-order block 20..34 (upper triangle over (s, e_y, e_psi, v, d_f), row-major)
+    DEV T linearize_frenet(const StageF<T> &S, bool exact)
+    {
+        const T dt = pt[PT_DT], Lb = pt[PT_LB], iLb = pt[PT_DTL] * rcp_(dt);
+        const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3], Cda2 = cwt[4], Cdd2 = cwt[5], Ca2 = cwt[6], Cd2 = cwt[7];
+        (void)Lb;
+        const int k = lane;
+        const bool st = k < N;
+        if (k <= N) {
+            T *q = lin + LSTR * k;
+            const T v = S.v, c = S.c, sn = S.s, K = S.K, Kp = S.Kp, iden = S.iden, dsdt = S.dsdt, ey = S.y, b1 = S.b1;
+            const T ds_s = v * c * ey * Kp * iden * iden, ds_ey = v * c * K * iden * iden, ds_ep = -v * sn * iden, ds_v = c * iden,
+                    ds_d = -v * sn * iden * b1;
+            q[0] = st ? (T)1 + dt * ds_s : (T)0; q[1] = st ? dt * ds_ey : (T)0; q[2] = st ? dt * ds_ep : (T)0; q[3] = st ? dt * ds_v : (T)0;
+            q[4] = st ? dt * v * c : (T)0; q[5] = st ? dt * sn : (T)0;
+            q[6] = st ? dt * (-ds_s * K - dsdt * Kp) : (T)0; q[7] = st ? -dt * ds_ey * K : (T)0;
+            q[8] = st ? (T)1 - dt * ds_ep * K : (T)0; q[9] = st ? dt * (S.sinb * iLb - ds_v * K) : (T)0;
+            q[10] = st ? dt * ds_d : (T)0; q[11] = st ? dt * v * c * b1 : (T)0; q[12] = st ? dt * (v * iLb * S.cosb * b1 - ds_d * K) : (T)0;
+            T *l = wb + 4 * k;  // stage cost gradient (wb is scratch here; stage_form_weights rewrites it later)
+            l[0] = Cx2 * S.ex; l[1] = Cy2 * S.ey; l[2] = Cp2 * S.ep; l[3] = Cv2 * S.ev;
+        }
+        WSYNC();
+        T l0 = wb[4 * N], l1 = wb[4 * N + 1], l2 = wb[4 * N + 2], l3 = wb[4 * N + 3];  // costate of state N
+        if (lane == 0) { T *ql = lin + LSTR * N + 16; ql[0] = l0; ql[1] = l1; ql[2] = l2; ql[3] = l3; }
+#pragma nounroll
+        for (int kk = N - 1; kk >= 0; --kk) {  // costates: a serial recursion on wave-uniform values
+            const T *q = lin + LSTR * kk;
+            if (lane == 0) { xb[2 * kk] = dt * l3; xb[2 * kk + 1] = q[10] * l0 + q[11] * l1 + q[12] * l2; }  // B_k^T lambda_{k+1}
+            const T t0 = q[0] * l0 + q[6] * l2;
+            const T t1 = q[1] * l0 + l1 + q[7] * l2;
+            const T t2 = q[2] * l0 + q[4] * l1 + q[8] * l2;
+            const T t3 = q[3] * l0 + q[5] * l1 + q[9] * l2 + l3;
+            const T *l = wb + 4 * kk;
+            l0 = t0 + l[0]; l1 = t1 + l[1]; l2 = t2 + l[2]; l3 = t3 + l[3];
+            if (lane == 0) { T *ql = lin + LSTR * kk + 16; ql[0] = l0; ql[1] = l1; ql[2] = l2; ql[3] = l3; }
+        }
+        WSYNC();
+        if (k <= N) {
+            T *q = lin + LSTR * k + 20;  // upper triangle, row-major: ss se sp sv sd | ee ep ev ed | pp pv pd | vv vd | dd
+            T m[15];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) m[i] = (T)0;
+            if (exact && st) {
+                // second derivatives of the Euler step wrt (s, e_y, e_psi, v, d_f), contracted with the costate of state k+1
+                const T *ln = lin + LSTR * (k + 1) + 16;
+                const T m0 = ln[0], m1 = ln[1], m2 = ln[2];
+                const T s_ = S.x, ey = S.y, v = S.v, C = S.c, Sn = S.s, K = S.K, K1 = S.Kp, K2 = (T)6 * kp0 * s_ + (T)2 * kp1;
+                const T D = S.iden, b1 = S.b1, b2 = S.b2, gq = S.dsdt;
+                const T Ds = ey * K1 * D * D, De = K * D * D;
+                const T Dss = ey * K2 * D * D + (T)2 * ey * K1 * D * Ds, Dse = K1 * D * D + (T)2 * ey * K1 * D * De, Dee = (T)2 * K * D * De;
+                const T g_s = v * C * Ds, g_e = v * C * De, g_p = -v * Sn * D, g_v = C * D, g_d = -v * Sn * b1 * D;
+                const T w = m0 - m2 * K, a2 = m2 * K1;
+                m[0] = dt * (w * (v * C * Dss) - (T)2 * a2 * g_s - m2 * gq * K2);
+                m[1] = dt * (w * (v * C * Dse) - a2 * g_e);
+                m[2] = dt * (w * (-v * Sn * Ds) - a2 * g_p);
+                m[3] = dt * (w * (C * Ds) - a2 * g_v);
+                m[4] = dt * (w * (-v * Sn * b1 * Ds) - a2 * g_d);
+                m[5] = dt * (w * (v * C * Dee));
+                m[6] = dt * (w * (-v * Sn * De));
+                m[7] = dt * (w * (C * De));
+                m[8] = dt * (w * (-v * Sn * b1 * De));
+                m[9] = dt * (w * (-v * C * D) + m1 * (-v * Sn));
+                m[10] = dt * (w * (-Sn * D) + m1 * C);
+                m[11] = dt * (w * (-v * C * b1 * D) + m1 * (-v * Sn * b1));
+                m[13] = dt * (w * (-Sn * b1 * D) + m1 * (C * b1) + m2 * (S.cosb * b1 * iLb));
+                m[14] = dt * (w * (v * D * (-C * b1 * b1 - Sn * b2)) + m1 * (v * (-Sn * b1 * b1 + C * b2)) + m2 * (v * (-S.sinb * b1 * b1 + S.cosb * b2) * iLb));
+            }
+#pragma unroll
+            for (int i = 0; i < 15; ++i) q[i] = m[i];   // zero when the Gauss-Newton matrix is wanted (and in record N)
+        }
+        // input-cost terms, Frenet.jl:99-102 (same as the Cartesian model)
+        const T aprev = dpp_mov0<0x138, 0xf>(S.a), dprev = dpp_mov0<0x138, 0xf>(S.d);  // wave_shr:1 -> lane-1
+        const T anext = dpp_mov0<0x130, 0xf>(S.a), dnext = dpp_mov0<0x130, 0xf>(S.d);
+        if (st) {
+            T ga = xb[2 * k] + Ca2 * S.a, gd = xb[2 * k + 1] + Cd2 * S.d;
+            if (k >= 1) { ga += Cda2 * (S.a - aprev); gd += Cdd2 * (S.d - dprev); }
+            if (k < N - 1) { ga -= Cda2 * (anext - S.a); gd -= Cdd2 * (dnext - S.d); }
+            xb[2 * k] = ga; xb[2 * k + 1] = gd;
+        }
+        WSYNC();
+        const T g = lane < n ? xb[lane] : (T)0;
+        WSYNC();
+        return g;
+    }
+
+    // Condensing with dense stage Jacobians: lane j keeps all four components of column j of G (16 FMAs per stage); the weight of the
+    // contraction is the full symmetric 4x4 block 2 Q_s + M_s^{zz}; the d_f rows of the second-order term go into the packed image as in
+    // the Cartesian model.  Same staging / MFMA pipeline as condense_trips (one basic block per number of live tile rows).
+    template <int ROWS> DEV void condense_trips_frenet(int s0, int s1, T (&g)[4], T (&fa)[NT], T (&fb)[NT], acc_t (&acc)[NTT], T sc)
+    {
+        const int kk = lane >> 4, c = lane & 15;
+        const T dtv = pt[PT_DT];
+        T *colK = Lc + offc_rt(lane < n ? lane : 0);
+        const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3];
+#pragma nounroll
+        for (int s = s0; s < s1; ++s) {
+            const T *q = lin + LSTR * s;           // Jacobians and d_f row of the second-order block of state s
+            const T *mn = lin + LSTR * (s + 1) + 20;  // state part of the second-order block of state s+1 (record N: zero)
+            const T A00 = q[0], A01 = q[1], A02 = q[2], A03 = q[3], A12 = q[4], A13 = q[5], A20 = q[6], A21 = q[7], A22 = q[8], A23 = q[9];
+            const T Bs = q[10], Bey = q[11], Bep = q[12];
+            const T msd = q[24], med = q[28], mpd = q[31], mvd = q[33], mdd = q[34];
+            const int rho = 2 * s + 1;
+            const T val = sc * (msd * g[0] + med * g[1] + mpd * g[2] + mvd * g[3]) + (lane == rho ? sc * mdd : (T)0);
+            T *dst = (lane <= rho && lane < n) ? colK + rho : xb + lane;
+            *dst = val;
+            // advance the recursion to state s+1: G_{s+1} = [A_s G_s | B_s]
+            const T n0 = A00 * g[0] + A01 * g[1] + A02 * g[2] + A03 * g[3];
+            const T n1 = g[1] + A12 * g[2] + A13 * g[3];
+            const T n2 = A20 * g[0] + A21 * g[1] + A22 * g[2] + A23 * g[3];
+            g[0] = n0; g[1] = n1; g[2] = n2;
+            if (lane == 2 * s) { g[0] = (T)0; g[1] = (T)0; g[2] = (T)0; g[3] = dtv; }
+            if (lane == 2 * s + 1) { g[0] = Bs; g[1] = Bey; g[2] = Bep; g[3] = (T)0; }
+            // products of state s (fragments requested at the end of the previous trip)
+#pragma unroll
+            for (int ti = 0; ti < ROWS; ++ti)
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj)
+                    acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc[ti * (ti + 1) / 2 + tj]);
+            // weights of state s+1
+            const T Cv1 = s + 1 <= N - 1 ? Cv2 : (T)0;
+            const T W00 = Cx2 + mn[0], W01 = mn[1], W02 = mn[2], W03 = mn[3], W11 = Cy2 + mn[5], W12 = mn[6], W13 = mn[7],
+                    W22 = Cp2 + mn[9], W23 = mn[10], W33 = Cv1 + mn[12];
+            opb[0 * 64 + lane] = g[0]; opb[1 * 64 + lane] = g[1]; opb[2 * 64 + lane] = g[2]; opb[3 * 64 + lane] = g[3];
+            opb[4 * 64 + lane] = W00 * g[0] + W01 * g[1] + W02 * g[2] + W03 * g[3];
+            opb[5 * 64 + lane] = W01 * g[0] + W11 * g[1] + W12 * g[2] + W13 * g[3];
+            opb[6 * 64 + lane] = W02 * g[0] + W12 * g[1] + W22 * g[2] + W23 * g[3];
+            opb[7 * 64 + lane] = W03 * g[0] + W13 * g[1] + W23 * g[2] + W33 * g[3];
+            WFENCE();
+#pragma unroll
+            for (int t = 0; t < (ROWS + 1 < NT ? ROWS + 1 : NT); ++t) {
+                fa[t] = opb[kk * 64 + 16 * t + c]; fb[t] = opb[(4 + kk) * 64 + 16 * t + c];
+            }
+        }
+    }
+    DEV void condense_frenet(T sc, acc_t (&acc)[NTT])
+    {
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        T g[4] = {0, 0, 0, 0}, fa[NT], fb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fa[t] = fb[t] = (T)0;
+        condense_trips_frenet<0>(0, 1, g, fa, fb, acc, sc);
+        condense_trips_frenet<1>(1, N < 9 ? N : 9, g, fa, fb, acc, sc);
+        if (NT >= 2 && N > 9) condense_trips_frenet<(NT >= 2 ? 2 : 1)>(9, N < 17 ? N : 17, g, fa, fb, acc, sc);
+        if (NT >= 3 && N > 17) condense_trips_frenet<(NT >= 3 ? 3 : 1)>(17, N < 25 ? N : 25, g, fa, fb, acc, sc);
+        if (NT >= 4 && N > 25) condense_trips_frenet<(NT >= 4 ? 4 : 1)>(25, N, g, fa, fb, acc, sc);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj)
+                acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc[ti * (ti + 1) / 2 + tj]);
     }
 
     // Condensing on the matrix cores.  H = sum_s G_s^T (2 Q_s + M_s^{psi,v}) G_s accumulates in `acc` (lower 16x16 tiles,
@@ -297,7 +533,7 @@ template <typename T, int N> struct FastSolver {
     struct Rec { T a02, a03, a12, a13, a23, bx, by, bp, mpp, mpv, mpd, mvd, mdd; };
     DEV void load_rec(Rec &r, int s) const
     {
-        const T *q = lin + LIN_STRIDE * s;  // record N is all zero (linearize)
+        const T *q = lin + LSTR * s;  // record N is all zero (linearize)
         r.a02 = q[0]; r.a03 = q[1]; r.a12 = q[2]; r.a13 = q[3]; r.a23 = q[4]; r.bx = q[5]; r.by = q[6]; r.bp = q[7];
         r.mpp = q[8]; r.mpv = q[9]; r.mpd = q[10]; r.mvd = q[11]; r.mdd = q[12];  // zero when the Gauss-Newton matrix is wanted
     }
@@ -366,11 +602,14 @@ template <typename T, int N> struct FastSolver {
     {
         T z = (T)0;
         pin(z);  // materialised here: hoisted out of the iteration loop this zero would occupy (and spill) a VGPR pair for the whole solve
-        if (lane <= N) { T *q = lin + LIN_STRIDE * lane; q[8] = z; q[9] = z; q[10] = z; q[11] = z; q[12] = z; }
+        if (MODEL == 1) {
+            if (lane <= N) { T *q = lin + LSTR * lane + 20; for (int i = 0; i < 15; ++i) q[i] = z; }
+        } else if (lane <= N) { T *q = lin + LSTR * lane; q[8] = z; q[9] = z; q[10] = z; q[11] = z; q[12] = z; }
         WSYNC();
     }
     DEV void condense(T sc, acc_t (&acc)[NTT])
     {
+        if constexpr (MODEL == 1) { condense_frenet(sc, acc); return; }
 #pragma unroll
         for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
         CondState S;
@@ -633,7 +872,8 @@ template <typename T, int N> struct FastSolver {
             len = dpp_sum(seg);
             kap = (readlane_(rp, N) - readlane_(rp, 1)) / fmax(len, (T)1e-6);
         }
-        const T vref = len / ((T)(N - 1) * dt);
+        if (MODEL == 1) kap = ((kp0 * x0 + kp1) * x0 + kp2) * x0 + kp3;  // Frenet: curvature of the polynomial at s0
+        const T vref = MODEL == 1 ? vt : len / ((T)(N - 1) * dt);
         const T sb = fmin(fmax(pt[PT_LB] * kap, (T)-0.9), (T)0.9);
         const T dff = fmin(fmax(atan(sb * rsqrt_((T)1 - sb * sb) / rr)  /* tan(asin(sb)) = sb / sqrt(1 - sb^2), |sb| <= 0.9 */, -frac * steer_max), frac * steer_max);
         const T aff = fmin(fmax(vref - v0, -frac * a_max), frac * a_max);
@@ -1036,6 +1276,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void km
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N>::lds_elems() * sizeof(T)];
     if ((int)blockIdx.x >= P.B) return;
     const int b = io.perm ? io.perm[blockIdx.x] : (int)blockIdx.x;
+#ifdef KMPC_POISON  // diagnostic build (make poison): every LDS word starts as NaN, so a read of a word nobody wrote shows up in the results
+    for (int e = threadIdx.x; e < FastSolver<T, N>::lds_elems(); e += 64) reinterpret_cast<T *>(smem)[e] = (T)NAN;
+    __syncthreads();
+#endif
     FastSolver<T, N> sv(P, smem);
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
     sv.solve(io, b);
@@ -1111,6 +1355,42 @@ static hipError_t launch_fast_n(const KP &P, const KIO<T> &io, hipStream_t st)
     hipLaunchKernelGGL((kmpc_solve_fast_kernel<T, N>), dim3(P.B), dim3(64), 0, st, P, io);
     return hipGetLastError();
 }
+
+// Frenet-frame functor (kmpc_config.model = 1): io.ref carries k_poly [B,4]
+template <typename T, int N>
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_frenet_kernel(KP P, KIO<T> io)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N, 1>::lds_elems() * sizeof(T)];
+    if ((int)blockIdx.x >= P.B) return;
+    const int b = io.perm ? io.perm[blockIdx.x] : (int)blockIdx.x;
+#ifdef KMPC_POISON
+    for (int e = threadIdx.x; e < FastSolver<T, N, 1>::lds_elems(); e += 64) reinterpret_cast<T *>(smem)[e] = (T)NAN;
+    __syncthreads();
+#endif
+    FastSolver<T, N, 1> sv(P, smem);
+    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
+    sv.solve(io, b);
+}
+template <typename T, int N>
+static hipError_t launch_fast_frenet_n(const KP &P, const KIO<T> &io, hipStream_t st)
+{
+    hipLaunchKernelGGL((kmpc_solve_fast_frenet_kernel<T, N>), dim3(P.B), dim3(64), 0, st, P, io);
+    return hipGetLastError();
+}
+template <typename T> hipError_t kmpc_launch_solve_fast_frenet(const KP &P, const KIO<T> &io, hipStream_t st)
+{
+    switch (P.N) {
+        case 8: return launch_fast_frenet_n<T, 8>(P, io, st);
+        case 12: return launch_fast_frenet_n<T, 12>(P, io, st);
+        case 16: return launch_fast_frenet_n<T, 16>(P, io, st);
+        case 20: return launch_fast_frenet_n<T, 20>(P, io, st);
+        case 24: return launch_fast_frenet_n<T, 24>(P, io, st);
+        case 28: return launch_fast_frenet_n<T, 28>(P, io, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template hipError_t kmpc_launch_solve_fast_frenet<double>(const KP &, const KIO<double> &, hipStream_t);
+template hipError_t kmpc_launch_solve_fast_frenet<float>(const KP &, const KIO<float> &, hipStream_t);
 
 // horizons with a compiled fast kernel; everything else runs the generic kernel
 // compile-time horizons: N % 4 == 0 and 2N + 1 <= 64

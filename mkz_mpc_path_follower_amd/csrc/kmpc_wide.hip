@@ -1013,6 +1013,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 2 : 4) void kmpc_solve_wide_k
     __shared__ __attribute__((aligned(16))) unsigned char smem[WideSolver<T, N>::lds_elems() * sizeof(T)];
     if ((int)blockIdx.x >= P.B) return;
     const int b = io.perm ? io.perm[blockIdx.x] : (int)blockIdx.x;
+#ifdef KMPC_POISON  // diagnostic build (make poison): every LDS word starts as NaN, so a read of a word nobody wrote shows up in the results
+    for (int e = threadIdx.x; e < WideSolver<T, N>::lds_elems(); e += 256) reinterpret_cast<T *>(smem)[e] = (T)NAN;
+    __syncthreads();
+#endif
     WideSolver<T, N> sv(P, smem);
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
     sv.solve(io, b);
