@@ -48,8 +48,13 @@ struct KDbgK {
 constexpr int KMPC_STG = 36;  // scalars stored per stage in LDS (Cartesian: 13; Frenet: 13 Jacobian + 3 roll-out + 4 costate + 15 Hessian)
 
 // LDS bytes the solver kernel needs for horizon N with NT column tiles
+#ifdef __HIPCC__
+#define KMPC_HD __host__ __device__
+#else
+#define KMPC_HD
+#endif
 template <typename T>
-inline size_t kmpc_lds_bytes(int N, int NT)
+KMPC_HD inline size_t kmpc_lds_bytes(int N, int NT)
 {
     const int n = 2 * N;
     const int NF = (40 * NT - 2 + 63) / 64;

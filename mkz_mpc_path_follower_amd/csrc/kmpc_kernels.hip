@@ -1191,6 +1191,11 @@ __global__ __launch_bounds__(64) void kmpc_solve_kernel(KP P, KIO<T> io)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= P.B) return;
     const int b = io.perm ? io.perm[blockIdx.x] : (int)blockIdx.x;
+#ifdef KMPC_POISON  // diagnostic build (make poison): every LDS word starts as NaN
+    { T *w_ = reinterpret_cast<T *>(smem); const int ne_ = (int)(kmpc_lds_bytes<T>(P.N, NT) / sizeof(T));
+      for (int e = threadIdx.x; e < ne_; e += 64) w_[e] = (T)NAN;
+      __syncthreads(); }
+#endif
     Solver<T, NT> sv(P, smem);
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
     sv.solve(io, b);
@@ -1202,6 +1207,11 @@ __global__ __launch_bounds__(64) void kmpc_solve_frenet_kernel(KP P, KIO<T> io)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= P.B) return;
     const int b = (int)blockIdx.x;
+#ifdef KMPC_POISON  // diagnostic build (make poison): every LDS word starts as NaN
+    { T *w_ = reinterpret_cast<T *>(smem); const int ne_ = (int)(kmpc_lds_bytes<T>(P.N, NT) / sizeof(T));
+      for (int e = threadIdx.x; e < ne_; e += 64) w_[e] = (T)NAN;
+      __syncthreads(); }
+#endif
     Solver<T, NT, 1> sv(P, smem);
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);  // io.ref = k_poly [B,4]
     sv.solve(io, b);

@@ -22,4 +22,14 @@ for dt in (torch.float64, torch.float32):
         o = BatchMPC(N=N, dtype=dt, model=1).solve_frenet(z0, kp, vt, up); torch.cuda.synchronize()
         nb = int((o["status"] != 0).sum()); bad += nb
         print("Frenet    %s N=%2d: not Optimal %d" % (str(dt)[6:], N, nb))
+for N, dt in ((13, torch.float64), (20, torch.float64), (50, torch.float64), (20, torch.float32), (33, torch.float32)):   # generic kernel (kernel_variant 1)
+    d = make_batch(256, N, cfg_id=2)
+    o = BatchMPC(N=N, dtype=dt, kernel_variant=1).solve(d["z0"], d["ref"], d["v_target"], d["u_prev"]); torch.cuda.synchronize()
+    nb = int((o["status"] != 0).sum()); bad += nb
+    print("generic Cartesian %s N=%2d: not Optimal %d" % (str(dt)[6:], N, nb))
+for N in (8, 20, 24):
+    z0, kp, vt, up = _cases(256, N, seed=5)
+    o = BatchMPC(N=N, dtype=torch.float64, model=1, kernel_variant=1).solve_frenet(z0, kp, vt, up); torch.cuda.synchronize()
+    nb = int((o["status"] != 0).sum()); bad += nb
+    print("generic Frenet float64 N=%2d: not Optimal %d" % (N, nb))
 print("TOTAL not Optimal:", bad)
