@@ -789,7 +789,7 @@ template <typename T, int N> struct WideSolver {
             asm volatile("" : "+v"(tid));
             lane = tid & 63;
             if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && cs[C_ERR] <= pt[PT_TOL])) {
-                Ut = tid < n ? ubl[tid] : (T)0; U = Ut; status = 0;
+                Ut = ubl[tid & 127]; U = Ut; status = 0;   // (threads >= 128 pick up copies: their U is never read as an input -- every use is guarded by tid < n)
             }
             if (mode != REFACTOR && mode != RESTEP) Jt = eval(Ut, St);
             STAMP(9);
@@ -863,7 +863,7 @@ template <typename T, int N> struct WideSolver {
                     const T gap_lim = pt[PT_GAP_TOL] * fmax((T)1, fabs(Jt));
                     cs[C_ERR] = err0; cs[C_RDS] = rdm * isd;
                     bool done = false;
-                    if (err0 <= tol) { if (tid < n) ubl[tid] = U; have_best = true; }
+                    if (err0 <= tol) { if (tid < 128) ubl[tid] = U; have_best = true; }
                     if (err0 <= tol) {
                         if (gap <= gap_lim * sc || n_polish >= 1) done = true; else ++n_polish;
                     } else if (n_polish > 0 && ++n_polish > 1) done = true;
