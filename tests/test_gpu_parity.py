@@ -89,6 +89,23 @@ def test_solver_options_match_oracle(oracle, N, opt):
     assert abs(r["iters"][ok].mean() - ro["iters"][ok].mean()) < 1.0
 
 
+@pytest.mark.parametrize("N", [8, 20, 50])
+def test_nondefault_cost_weights_match_oracle(oracle, N):
+    """update_cost (MKZMPCPathFollower.jl:158-169) with every weight away from the node's (9, 9, 10, 0, 100, 1000, 0, 0): C_x != C_y, a
+    speed weight (terminal speed excluded, Q3), input weights -- through the same kernels, against the CPU checker with the same weights."""
+    O = oracle
+    B = 96 if N < 50 else 48
+    d = make_batch(B, N, cfg_id=10)
+    for w in ((4.0, 12.0, 25.0, 3.0, 40.0, 600.0, 0.7, 15.0), (1.0, 1.0, 1.0, 10.0, 10.0, 10.0, 1.0, 1.0)):
+        r = _solve(N, d, weights=w)
+        ro = O.solve_condensed_batch(O.params(N, w), d["z0"], d["ref"], d["v_target"], d["u_prev"], nthreads=8, want_X=True)
+        assert (ro["status"] == 0).all() and (r["status"] == 0).all(), (np.bincount(r["status"]), np.bincount(ro["status"]))
+        rel = np.abs(r["cost"] - ro["cost"]) / np.maximum(1.0, np.abs(ro["cost"]))
+        assert rel.max() <= 1e-6, rel.max()
+        assert r["viol"].max() <= 1e-8 + 1e-12 and np.abs(r["u0"] - ro["U"][:, 0, :]).max() <= 1e-6
+        assert np.abs(r["X"] - ro["X"]).max() <= 1e-4
+
+
 def test_batch_fp32(oracle):
     O = oracle
     N, B = 20, 256
