@@ -106,6 +106,25 @@ def test_nondefault_cost_weights_match_oracle(oracle, N):
         assert np.abs(r["X"] - ro["X"]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("N", [8, 20, 50])
+def test_nondefault_model_constants_match_oracle(oracle, N):
+    """the module-level constants of MKZMPCPathFollower.jl:28-48 away from their values (kmpc_config): model step, control period,
+    axle distances, every limit -- incl. a tyre-angle limit beyond the polynomial sin/cos range (steer_max = 1.0: library path)"""
+    O = oracle
+    B = 64 if N < 50 else 32
+    d = make_batch(B, N, cfg_id=11, dt=0.15)
+    kw = dict(dt=0.15, dt_control=0.05, L_a=1.3, L_b=1.5, steer_max=1.0, steer_dmax=0.8, a_max=1.6, a_dmax=2.5, v_min=0.5, v_max=14.0)
+    d["z0"][:, 3] = np.clip(d["z0"][:, 3], 0.6, 13.9)
+    d["u_prev"][:, 0] = np.maximum(d["u_prev"][:, 0], -(d["z0"][:, 3] - 0.5) / 0.15 + 0.2)   # keep the first-step speed row feasible
+    r = _solve(N, d, **kw)
+    ro = O.solve_condensed_batch(O.params(N, **kw), d["z0"], d["ref"], d["v_target"], d["u_prev"], nthreads=8, want_X=True)
+    assert (ro["status"] == 0).all() and (r["status"] == 0).all(), (np.bincount(r["status"]), np.bincount(ro["status"]))
+    rel = np.abs(r["cost"] - ro["cost"]) / np.maximum(1.0, np.abs(ro["cost"]))
+    assert rel.max() <= 1e-6, rel.max()
+    assert r["viol"].max() <= 1e-8 * 14.0 + 1e-12 and np.abs(r["u0"] - ro["U"][:, 0, :]).max() <= 1e-6
+    assert np.abs(r["X"] - ro["X"]).max() <= 1e-4
+
+
 def test_batch_fp32(oracle):
     O = oracle
     N, B = 20, 256
