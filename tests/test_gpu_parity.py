@@ -125,6 +125,31 @@ def test_nondefault_model_constants_match_oracle(oracle, N):
     assert np.abs(r["X"] - ro["X"]).max() <= 1e-4
 
 
+def test_reused_output_dict_is_validated():
+    """an `out` dict left over from a call with another batch size / element type must not reach the kernel as raw pointers:
+    tensors that do not fit are replaced, fitting ones are reused (no allocation in the timed path)."""
+    from mkz_mpc_path_follower_amd import BatchMPC
+    N = 8
+    d = make_batch(64, N, cfg_id=3)
+    s = BatchMPC(N=N)
+    o = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"], want_U=True)
+    ptr = o["u0"].data_ptr()
+    o2 = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"], want_U=True, out=o)
+    assert o2["u0"].data_ptr() == ptr                                      # same size: reused
+    half = {k: v[:32] for k, v in d.items()}
+    o3 = s.solve(half["z0"], half["ref"], half["v_target"], half["u_prev"], want_U=True, want_X=True, out=o2)
+    torch.cuda.synchronize()
+    assert o3["u0"].shape == (32, 2) and o3["U"].shape == (32, N, 2) and o3["X"].shape == (32, N + 1, 4) and (o3["status"] == 0).all()
+    big = make_batch(200, N, cfg_id=3)
+    o4 = s.solve(big["z0"], big["ref"], big["v_target"], big["u_prev"], out=o3)   # larger batch into the smaller buffers
+    torch.cuda.synchronize()
+    assert o4["u0"].shape == (200, 2) and (o4["status"] == 0).all() and torch.isfinite(o4["cost"]).all()
+    s32 = BatchMPC(N=N, dtype=torch.float32)
+    o5 = s32.solve(big["z0"], big["ref"], big["v_target"], big["u_prev"], out=o4)  # other element type
+    torch.cuda.synchronize()
+    assert o5["u0"].dtype == torch.float32 and (o5["status"] == 0).all()
+
+
 def test_batch_fp32(oracle):
     O = oracle
     N, B = 20, 256
