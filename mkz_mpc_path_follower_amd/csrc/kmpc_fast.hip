@@ -63,7 +63,7 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
     const KP &P;
     int lane;  // re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the
                // lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
-    T *Lc, *xb, *wb, *cb, *lin, *opb, *cs, *ubest, *gb, *cub, *clb, *sinvb;
+    T *Lc, *xb, *wb, *cb, *lin, *opb, *gnb, *cs, *ubest, *gb, *cub, *clb, *sinvb;
     Coef<T> kc;  // polynomial coefficients (LDS table in fp64)
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff, yoff;
     T kp0, kp1, kp2, kp3;  // Frenet: K(s) = kp0 s^3 + kp1 s^2 + kp2 s + kp3
@@ -84,6 +84,7 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
         cb = wb + 64 * NF;
         lin = cb + 64;
         opb = lin + LSTR * (N + 1);
+        gnb = opb + 4 * 64;     // terminal sensitivities G_N [3][64] (Cartesian model): the Cholesky panel scratch uses opb[0 .. 4 * 64) only
         cs = opb + 8 * 64;      // wave-uniform scalars that are read once or twice per iteration live here, not in VGPRs
         ubest = cs + 16;        // last iterate that passed Ipopt's test
         gb = ubest + 64;        // gradient of the current linearisation (lane j: g_j)
@@ -285,6 +286,22 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
         if (k >= 1) { ga += Cda2 * (S.a - aprev); gd += Cdd2 * (S.d - dprev); }
         if (k < N - 1) { ga -= Cda2 * (anext - S.a); gd -= Cdd2 * (dnext - S.d); }
         if (st) { xb[2 * k] = ga; xb[2 * k + 1] = gd; }
+        if (ADJ) {
+            // Terminal sensitivities for condense_adjoint: column j of G_N = Phi(N, k+1) B_k e_j, k = j / 2.  The stage Jacobians are unit
+            // upper triangular (x, y <- psi, v; psi <- v), so the transition matrix is made of suffix sums over the later stages:
+            //   d psi_N / d v = P3(k) = sum_{s>k} A23_s,   d x_N / d psi = X2(k) = sum_{s>k} A02_s,
+            //   d x_N / d v = sum_{s>k} [A03_s + A02_s (P3(k) - R_s)],  R_s = sum_{t>=s} A23_t          (y alike)
+            const T R = dpp_scan_suffix<SROWS>(A23, lane);
+            const T ux = A03 - A02 * R, uy = A13 - A12 * R;
+            const T X2 = dpp_scan_suffix<SROWS>(A02, lane) - A02, Y2 = dpp_scan_suffix<SROWS>(A12, lane) - A12;
+            const T zx = dpp_scan_suffix<SROWS>(ux, lane) - ux, zy = dpp_scan_suffix<SROWS>(uy, lane) - uy;
+            const T P3 = R - A23;
+            if (st) {
+                T *q = gnb + 2 * k;
+                q[0] = dt * fma(P3, X2, zx); q[64] = dt * fma(P3, Y2, zy); q[128] = dt * P3;   // acceleration column: B = (0, 0, 0, dt)
+                q[1] = fma(X2, Bdp, Bdx); q[65] = fma(Y2, Bdp, Bdy); q[129] = Bdp;               // steering column
+            }
+        }
         T mpp = 0, mpv = 0, mpd = 0, mvd = 0, mdd = 0;
         if (exact && st) {
             const T v = S.v, c = S.c, s = S.s, b1 = S.b1, b2 = S.b2;
@@ -607,9 +624,60 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
         } else if (lane <= N) { T *q = lin + LSTR * lane; q[8] = z; q[9] = z; q[10] = z; q[11] = z; q[12] = z; }
         WSYNC();
     }
+    // Condensing in O(N^2) (Cartesian model): column j of sc * H, H = sum_s G_s^T W_s G_s + the second-order d_f rows, by an ADJOINT
+    // recursion with lane j = column j -- no matrix product at all:
+    //   start   : column j of G_N, the sensitivity of the terminal state (closed form in suffix sums of the stage Jacobians: linearize);
+    //   backward: p(s) = sum_{k >= s} Phi(k,s)^T W_k G_k[:,j] = W_s G_s[:,j] + A_s^T p(s+1), and with it the two rows of stage s,
+    //             H[2s][j] = dt p_v(s+1),  H[2s+1][j] = B_s^T p(s+1) + (mpd, mvd) . G_s[(psi, v), j]   (the m_dd diagonal: build_tiles);
+    //             G_s[:,j] comes from G_{s+1}[:,j] through the exact inverse of the unit upper-triangular A_s (5 FMAs, nothing stored).
+    // Each lane writes its column (rows >= j) of the packed K image; build_tiles reads the tiles from there.  A lane whose column is
+    // born at stage j/2 carries meaningless (finite) values below that stage; they are never stored.
+    DEV void condense_adjoint(T sc)
+    {
+        const T dtv = pt[PT_DT];
+        const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3];
+        // column j of G_N: linearize left it in the table (it depends on the linearisation only, not on the barrier weights or the shift);
+        // everything downstream is linear in G, so the scaling of the objective goes in here, once
+        const int jr = lane < n ? lane : 0;
+        T gx = sc * gnb[jr], gy = sc * gnb[64 + jr], gp = sc * gnb[128 + jr], gv = (lane & 1) ? (T)0 : sc * dtv;
+        // p(N) = W_N G_N: no second-order part and no speed cost on the terminal state
+        T px = Cx2 * gx, py = Cy2 * gy, pp = Cp2 * gp, pv = (T)0;
+        // lane j is alive while 2s+1 >= j.  Lane 2s+1 has no row 2s: its store lands on (row n, column 2s) of the image -- the rhs row, which
+        // nobody reads before the factorisation writes it -- so one address serves both rows
+        T *colK = Lc + offc_rt(lane < n ? lane : 0);
+        Rec cur;
+        load_rec(cur, N - 1);
+#pragma unroll 2
+        for (int s = N - 1; s >= 0; --s) {
+            Rec nxt;
+            load_rec(nxt, s > 0 ? s - 1 : 0);
+            const T ra = dtv * pv;
+            T rd = fma(cur.bp, pp, fma(cur.by, py, cur.bx * px));
+            // G_s from G_{s+1}
+            gp = fma(-cur.a23, gv, gp);
+            gx = fma(-cur.a03, gv, fma(-cur.a02, gp, gx));
+            gy = fma(-cur.a13, gv, fma(-cur.a12, gp, gy));
+            const T cross = fma(cur.mvd, gv, cur.mpd * gp);
+            rd += lane < 2 * s ? cross : (T)0;   // G_s is exactly zero in columns 2s, 2s+1 (what the lanes hold there is not)
+            if (lane <= 2 * s + 1 && lane < n) { colK[2 * s] = ra; colK[2 * s + 1] = rd; }
+            // p(s) = A_s^T p(s+1) + W_s G_s  (states 1 .. N-1 carry the speed weight; p(0) is never used)
+            pv = fma(cur.a23, pp, fma(cur.a13, py, fma(cur.a03, px, pv)));
+            pp = fma(cur.a12, py, fma(cur.a02, px, pp));
+            px = fma(Cx2, gx, px);
+            py = fma(Cy2, gy, py);
+            pp = fma(cur.mpv, gv, fma(Cp2 + cur.mpp, gp, pp));
+            pv = fma(cur.mpv, gp, fma(Cv2, gv, pv));
+            cur = nxt;
+        }
+        WSYNC();
+    }
     DEV void condense(T sc, acc_t (&acc)[NTT])
     {
         if constexpr (MODEL == 1) { condense_frenet(sc, acc); return; }
+#ifndef KMPC_CONDENSE_MFMA
+        condense_adjoint(sc);
+        return;
+#endif
 #pragma unroll
         for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
         CondState S;
@@ -638,6 +706,11 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
     // entries, which lane j computes together with the input-cost Hessian (MKZMPCPathFollower.jl:99-102) and hands over through
     // a 2 x n staging buffer.  The second-order ODD rows come from the packed image, where condense put them.
     static constexpr int NTF = (n + 1 + 15) / 16, NTTF = NTF * (NTF + 1) / 2;
+#ifdef KMPC_CONDENSE_MFMA
+    static constexpr bool ADJ = false;
+#else
+    static constexpr bool ADJ = MODEL == 0;  // the whole lower triangle of sc*H is in the packed image (condense_adjoint), nothing in kt
+#endif
     // In place: on entry the first NTT tiles of kt are the accumulators of condense (same packed lower-triangular tile order).
     DEV void build_tiles(T sc, T reg, acc_t (&kt)[NTTF])
     {
@@ -648,6 +721,7 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
             const int j = lane, jj = j & 1, k = j >> 1;
             const T Cu2 = cwt[jj ? 7 : 6], Cdl2 = cwt[jj ? 5 : 4];
             T dg = wb[j] + sc * (Cu2 + Cdl2 * (T)((k > 0) + (k < N - 1))) + reg;
+            if (ADJ && jj) dg += sc * lin[LSTR * k + 12];  // m_dd of stage k: the second-order (d_f, d_f) entry
             if (j < 2) dg += wb[n + j];
             if (j >= 4) dg += wb[n + j - 2];
             const bool rate = j >= 2 && j < R;
@@ -673,8 +747,9 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
                     T v = (T)0;
                     if (ti < NT) {
                         const T evm = (!oddrow && !(c & 1)) ? dt2 : (T)0;
-                        v = fma(sc, kt[ti * (ti + 1) / 2 + tj][r], evm * cb[(ti == NTF - 1 ? (row < n ? row : 0) : row) >> 1]);
-                        bool rd = oddrow;
+                        v = evm * cb[(ti == NTF - 1 ? (row < n ? row : 0) : row) >> 1];
+                        if (!ADJ) v = fma(sc, kt[ti * (ti + 1) / 2 + tj][r], v);
+                        bool rd = ADJ || oddrow;
                         if (ti == NTF - 1) rd = rd && row < n;
                         if (ti == tj) rd = rd && col <= row;
                         if (tj == NTF - 1) rd = rd && colok;
@@ -1133,7 +1208,10 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
                 acc_t kt[NTTF];  // condense accumulates into the first NTT tiles; build_tiles turns them into K in place
                 acc_t (&acc)[NTT] = reinterpret_cast<acc_t (&)[NTT]>(kt);
                 condense(sc, acc);
-                if (use_exact && indef == 1 && first_attempt) {  // max |sc * H_jj| over the diagonal of the tiles: scale of the delta_w shift
+                if (ADJ) {
+                    if (use_exact && indef == 1 && first_attempt)  // max |sc * H_jj|: scale of the delta_w shift
+                        cs[C_HMAX] = dpp_max_nn(lane < n ? fabs(Lc[offc_rt(lane) + lane]) : (T)0);
+                } else if (use_exact && indef == 1 && first_attempt) {  // max |sc * H_jj| over the diagonal of the tiles
                     T hm = 0;
 #pragma unroll
                     for (int ti = 0; ti < NT; ++ti)
