@@ -50,7 +50,7 @@ template <typename T, int N> struct WideSolver {
     STAMP_MEMBERS
     const KP &P;
     int tid, lane, wv;
-    T *Lc, *opb, *pan, *dgs, *sbs, *lin, *xb, *wb, *cb, *red, *sinvb, *x2, *x3, *gbl, *ubl, *cs;
+    T *Lc, *opb, *pan, *dgs, *sbs, *gnb, *lin, *xb, *wb, *cb, *red, *sinvb, *x2, *x3, *gbl, *ubl, *cs;
     Coef<T> kc;
     const T *pt, *cwt;
     int rpar;
@@ -70,7 +70,8 @@ template <typename T, int N> struct WideSolver {
         cs = base + O_CS + 16 * wv;    // wave-uniform scalars that are read once or twice per iteration: every wave parks its own copy
         pan = opb;                      // the Cholesky panel (2 x 4 NP) and the 2 x n staging of build_tiles alias the condensing
         dgs = opb + 2 * 4 * NP; sbs = dgs + 128;  // staging buffer: the three are live one after the other
-        static_assert(2 * 4 * NP + 256 <= 2 * 8 * NP, "aliases fit the fragment staging buffer");
+        gnb = sbs + 128;                // terminal sensitivities G_N [3][128], written by linearize, read by every condense of that linearisation
+        static_assert(2 * 4 * NP + 256 + 3 * 128 <= 2 * 8 * NP, "panel, build staging and the G_N table fit the buffer");
         for (int e = tid; e < 16 * NB; e += 256) sinvb[e] = (T)0;
         kc.tab = base + O_KC;
         if (sizeof(T) == 8 && tid < KC_COUNT) const_cast<T *>(kc.tab)[tid] = (T)kmpc_coef[tid];
@@ -277,7 +278,18 @@ template <typename T, int N> struct WideSolver {
             mdd = px1 * (-dt * v * (c * b1 * b1 + s * b2)) + py1 * (dt * v * (-s * b1 * b1 + c * b2)) +
                   pp1 * (dtL * v * (-S.sinb * b1 * b1 + S.cosb * b2));
         }
+        // terminal sensitivities for condense_adjoint (closed form in suffix sums of the unit upper-triangular stage Jacobians: kmpc_fast.hip)
+        const T Rs = dpp_scan_suffix<SROWS>(A23, lane);
+        const T ux = A03 - A02 * Rs, uy = A13 - A12 * Rs;
+        const T X2 = dpp_scan_suffix<SROWS>(A02, lane) - A02, Y2 = dpp_scan_suffix<SROWS>(A12, lane) - A12;
+        const T zx = dpp_scan_suffix<SROWS>(ux, lane) - ux, zy = dpp_scan_suffix<SROWS>(uy, lane) - uy;
+        const T P3 = Rs - A23;
         if (wv == 0) {
+            if (st) {
+                T *q = gnb + 2 * k;
+                q[0] = dt * fma(P3, X2, zx); q[128] = dt * fma(P3, Y2, zy); q[256] = dt * P3;   // acceleration column: B = (0, 0, 0, dt)
+                q[1] = fma(X2, Bdp, Bdx); q[129] = fma(Y2, Bdp, Bdy); q[257] = Bdp;               // steering column
+            }
             if (st) { gbl[2 * k] = ga; gbl[2 * k + 1] = gd; }
             if (k <= N) {
                 T *q = lin + WLIN * k;
@@ -305,6 +317,41 @@ template <typename T, int N> struct WideSolver {
         const T *q = lin + WLIN * s;  // record N is all zero (linearize)
         r.a02 = q[0]; r.a03 = q[1]; r.a12 = q[2]; r.a13 = q[3]; r.a23 = q[4]; r.bx = q[5]; r.by = q[6]; r.bp = q[7];
         r.mpp = q[8]; r.mpv = q[9]; r.mpd = q[10]; r.mvd = q[11]; r.mdd = q[12];
+    }
+    // Condensing in O(N^2): thread j < n carries column j of sc * H through the adjoint recursion (kmpc_fast.hip, condense_adjoint) and
+    // writes rows >= j of it into the packed image; no barrier inside (the stage records and the G_N table were published by linearize).
+    DEV void condense_adjoint(T sc)
+    {
+        if (tid < n) {
+            const T dtv = pt[PT_DT];
+            const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3];
+            T gx = sc * gnb[tid], gy = sc * gnb[128 + tid], gp = sc * gnb[256 + tid], gv = (tid & 1) ? (T)0 : sc * dtv;
+            T px = Cx2 * gx, py = Cy2 * gy, pp = Cp2 * gp, pv = (T)0;   // p(N) = W_N G_N
+            T *colK = Lc + offc_rt(tid);
+            Rec cur;
+            load_rec(cur, N - 1);
+#pragma unroll 2
+            for (int s = N - 1; s >= 0; --s) {
+                Rec nxt;
+                load_rec(nxt, s > 0 ? s - 1 : 0);
+                const T ra = dtv * pv;
+                T rd = fma(cur.bp, pp, fma(cur.by, py, cur.bx * px));
+                gp = fma(-cur.a23, gv, gp);   // G_s from G_{s+1}: exact inverse of the unit upper-triangular A_s
+                gx = fma(-cur.a03, gv, fma(-cur.a02, gp, gx));
+                gy = fma(-cur.a13, gv, fma(-cur.a12, gp, gy));
+                const T cross = fma(cur.mvd, gv, cur.mpd * gp);
+                rd += tid < 2 * s ? cross : (T)0;
+                if (tid <= 2 * s + 1) { colK[2 * s] = ra; colK[2 * s + 1] = rd; }  // thread 2s+1's row 2s lands on (row n, column 2s): unread until the factor writes it
+                pv = fma(cur.a23, pp, fma(cur.a13, py, fma(cur.a03, px, pv)));
+                pp = fma(cur.a12, py, fma(cur.a02, px, pp));
+                px = fma(Cx2, gx, px);
+                py = fma(Cy2, gy, py);
+                pp = fma(cur.mpv, gv, fma(Cp2 + cur.mpp, gp, pp));
+                pv = fma(cur.mpv, gp, fma(Cv2, gv, pv));
+                cur = nxt;
+            }
+        }
+        WGSYNC();
     }
     // Tile rows of wave W (compile-time in everything below: each wave runs its own specialisation, selected once per
     // factorisation by a switch on the wave number; tile indices, liveness tests and register arrays are then all static)
@@ -409,8 +456,7 @@ template <typename T, int N> struct WideSolver {
                     T v = (T)0;
                     if (colok && row < n && col <= row) {
                         const T evm = (!(row & 1) && !(col & 1)) ? dt2 : (T)0;
-                        v = fma(sc, kt[tj][r], evm * cb[row >> 1]);
-                        if (row & 1) v += colK[row];
+                        v = fma(evm, cb[row >> 1], colK[row]);
                         if (row == col) v += dgv;
                         if (row == col + 2) v += sbv;
                     } else if (colok && row == n) v = rhv;
@@ -426,6 +472,7 @@ template <typename T, int N> struct WideSolver {
             const int j = tid, jj = j & 1, k = j >> 1;
             const T Cu2 = cwt[jj ? 7 : 6], Cdl2 = cwt[jj ? 5 : 4];
             T dg = wb[j] + sc * (Cu2 + Cdl2 * (T)((k > 0) + (k < N - 1))) + reg;
+            if (jj) dg += sc * lin[WLIN * k + 12];  // m_dd of stage k: the second-order (d_f, d_f) entry
             if (j < 2) dg += wb[n + j];
             if (j >= 4) dg += wb[n + j - 2];
             const bool rate = j >= 2 && j < R;
@@ -551,20 +598,6 @@ template <typename T, int N> struct WideSolver {
     {
         constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
         acc_t k0[Rows<W>::N0], k1[Rows<W>::N1];
-        condense<W>(sc, k0, k1);
-        STAMP(3);
-        if (want_hmax) {  // max |sc * H_jj|: scale of the delta_w shift (diagonal tiles (R0, R0) and (R1, R1))
-            T hm = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (Real<T>::row_of(lane, r) == (lane & 15)) {
-                    if (16 * R0 + (lane & 15) < n) hm = fmax(hm, fabs(sc * k0[R0][r]));
-                    if (R1 >= 0) hm = fmax(hm, fabs(sc * k1[R1 >= 0 ? R1 : 0][r]));
-                }
-            T dm[1] = {(T)0}, hx[1] = {hm};
-            wg_reduce<0, 1>(dm, hx);
-            hmax = hx[0];
-        }
         build_tiles<W>(sc, reg, k0, k1);
         STAMP(4);
         if (Kdump) {  // diagnostics only (kmpc_debug_kkt): the assembled matrix, full symmetric n x n
@@ -894,6 +927,13 @@ template <typename T, int N> struct WideSolver {
                 {
                     const bool want_hmax = use_exact && indef == 1 && first_attempt;
                     T hmax = cs[C_HMAX];
+                    condense_adjoint(sc);
+                    STAMP(3);
+                    if (want_hmax) {  // max |sc * H_jj|: scale of the delta_w shift
+                        T dm[1] = {(T)0}, hx[1] = {tid < n ? fabs(Lc[offc_rt(tid) + tid]) : (T)0};
+                        wg_reduce<0, 1>(dm, hx);
+                        hmax = hx[0];
+                    }
                     switch (wv) {   // every wave runs the specialisation for its tile rows; the barriers inside pair up across them
                         case 0: factored = assemble_factor<0>(sc, reg, want_hmax, hmax); break;
                         case 1: factored = assemble_factor<1>(sc, reg, want_hmax, hmax); break;
@@ -1042,6 +1082,7 @@ __global__ __launch_bounds__(256, 2) void kmpc_wide_kkt_kernel(KP P, KDbgK<T> io
     T hm = 0;
     T *K = io.K + (size_t)b * n * n;
     bool okf;
+    sv.condense_adjoint(sc);
     switch (sv.wv) {
         case 0: okf = sv.template assemble_factor<0>(sc, reg, false, hm, K); break;
         case 1: okf = sv.template assemble_factor<1>(sc, reg, false, hm, K); break;
