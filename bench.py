@@ -41,6 +41,15 @@ def algorithmic_flops_per_iteration(N):
     return 150 * N + 32 * N * N + f_cond + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
 
 
+def executed_flops_per_iteration(N):
+    # what the kernels execute since round 2: condensing by the O(N^2) adjoint recursion -- per stage and live column 5 FMAs to recover G_s,
+    # 4 for the two Hessian rows, 2 for the second-order row, 5 for A^T p, 10 for W G (52 flops), columns 0..2s+1 live at stage s -- plus the
+    # suffix scans of the terminal sensitivities (~40 N); linearisation and the IPM step as in SURVEY.md 8(d).  The SURVEY formula (above)
+    # stays the numerator of `roofline.frac` so that rounds compare; this one says how much arithmetic is actually issued.
+    n, m = 2 * N, 10 * N - 4
+    return 150 * N + 52 * N * (N + 1) + 40 * N + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
+
+
 def measured_traffic_bytes():
     """(HBM bytes per 4096-problem dispatch, source) from the committed PMC passes (profiles/r*_pmc_traffic.json), or (None, None).
     PMC counters need their own rocprofv3 passes (tools/pmc_quick.sh); this run does not collect them -- the figure is the
@@ -347,7 +356,11 @@ def main():
                          "achieved": ach_tf, "peak": (FP64_PEAK_TFLOPS if a.dtype == "f64" else FP32_PEAK_TFLOPS), "unit": "TFLOP/s",
                          "frac": ach_tf / (FP64_PEAK_TFLOPS if a.dtype == "f64" else FP32_PEAK_TFLOPS), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name(N, a.dtype), "kernel_ms": kern_ms,
-                         "flops_per_solve": algorithmic_flops_per_iteration(N) * iters},
+                         "flops_per_solve": algorithmic_flops_per_iteration(N) * iters,
+                         "executed_flops_per_solve": executed_flops_per_iteration(N) * iters,
+                         "frac_executed": executed_flops_per_iteration(N) * iters * Bl / (kern_ms * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS if a.dtype == "f64" else FP32_PEAK_TFLOPS),
+                         "flops_note": "frac prices the SURVEY 8(d) flop model (O(N^3) structured condensing, 16 k^2 per stage); the kernels condense in O(N^2) "
+                                       "(adjoint recursion), frac_executed prices the arithmetic they actually issue"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": byts,
                              "bytes_per_solve": algorithmic_bytes_per_solve(N, es)},

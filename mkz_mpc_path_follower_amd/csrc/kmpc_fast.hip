@@ -16,9 +16,11 @@
 //     in VGPRs (-> LDS coefficient table), canonicalising v_max in front of fmax on DPP results
 //     (-> raw v_max), selects (-> 0/1 masks, exec-masked regions), IEEE divisions (-> rcp + Newton);
 //   * no ds_bpermute / LDS round trips for scans and reductions: DPP row_shr / row_shl / row_bcast;
-//   * condensing: the sensitivity recursion runs once per column (lane j = column j), its MFMA
-//     fragments are staged through a small LDS buffer, v_mfma_f64_16x16x4_f64 accumulates lower
-//     16x16 tiles; the KKT matrix is completed IN those registers (barrier terms, shift, rhs row);
+//   * condensing (Cartesian model) in O(N^2): lane j carries column j of the Hessian through an
+//     adjoint recursion over the stages (condense_adjoint; ~30 instructions per stage, no matrix
+//     product); the Frenet functor, whose stage Jacobians are dense, contracts G^T W G on the matrix
+//     cores (condense_frenet).  The KKT matrix is completed in the MFMA C-layout tile registers
+//     (barrier terms, shift, rhs row);
 //   * Cholesky: 4-column panels on the matrix cores (the 4x4 diagonal block redundantly in every
 //     lane, panel rows in MFMA fragment layout, one MFMA per trailing tile); what is stored (packed
 //     column-major LDS image, n(n+3)/2 words, 6.9 KB at N = 20) is the block-LDL^T form L~ = L D^-1,
@@ -43,7 +45,8 @@ constexpr int LIN_STRIDE = 16;
 // MODEL 0: Cartesian kinematic bicycle (MKZMPCPathFollower.jl); MODEL 1: Frenet-frame functor (MKZMPCPathFollowerFrenet.jl:112-123): states
 // (s, e_y, e_psi, v) in the (x, y, psi, v) slots, zero cost references, curvature polynomial K(s); only roll-out, costates and the
 // sensitivity recursion differ (the dynamics couple s, e_y, e_psi, so they are serial recursions on wave-uniform values and the stage
-// Jacobians are dense) -- forms, barrier method, MFMA contraction, KKT assembly, factorisation and substitutions are shared.
+// Jacobians are dense, and the condensing is a matrix-core contraction instead of the adjoint recursion) -- forms, barrier method, KKT
+// assembly, factorisation and substitutions are shared.
 template <typename T, int N, int MODEL = 0> struct FastSolver {
     static constexpr int LSTR = MODEL == 1 ? KMPC_STG : LIN_STRIDE;  // stage record stride (Frenet: 13 Jacobian + 3 roll-out + 4 costate + 15 Hessian)
     static constexpr int n = 2 * N, R = 2 * (N - 1), nf = 5 * N - 2;
@@ -470,9 +473,13 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
         return g;
     }
 
-    // Condensing with dense stage Jacobians: lane j keeps all four components of column j of G (16 FMAs per stage); the weight of the
-    // contraction is the full symmetric 4x4 block 2 Q_s + M_s^{zz}; the d_f rows of the second-order term go into the packed image as in
-    // the Cartesian model.  Same staging / MFMA pipeline as condense_trips (one basic block per number of live tile rows).
+    // Condensing with dense stage Jacobians, on the matrix cores: H = sum_s G_s^T (2 Q_s + M_s^{zz}) G_s accumulates in `acc` (lower 16x16
+    // tiles, MFMA C layout, unscaled).  Lane j keeps all four components of column j of G (16 FMAs per stage); each stage's MFMA fragments
+    // -- A = G_s, B = (2 Q_s + M_s) G_s with the full symmetric 4x4 weight -- go through a small component-major LDS buffer (opb[8][64]:
+    // conflict-free writes by column, conflict-free reads in fragment layout), software-pipelined: while the fragments of stage s are in
+    // flight / on the matrix cores the VALU advances the recursion.  Trips with the same number of live tile rows share one basic block.
+    // The d_f rows of the second-order term (every ODD row of the image) are written, scaled, straight into the packed K image by the
+    // lane of each column; build_tiles reads them back into the C-layout tiles.
     template <int ROWS> DEV void condense_trips_frenet(int s0, int s1, T (&g)[4], T (&fa)[NT], T (&fb)[NT], acc_t (&acc)[NTT], T sc)
     {
         const int kk = lane >> 4, c = lane & 15;
@@ -538,80 +545,13 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
                 acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc[ti * (ti + 1) / 2 + tj]);
     }
 
-    // Condensing on the matrix cores.  H = sum_s G_s^T (2 Q_s + M_s^{psi,v}) G_s accumulates in `acc` (lower 16x16 tiles,
-    // MFMA C layout, unscaled).  The sensitivity recursion G_s = [A_{s-1} G_{s-1} | B_{s-1}] runs ONCE PER COLUMN
-    // (lane j = column j keeps its 4 components: 5 FMAs per stage); each stage's MFMA fragments -- A = G_s,
-    // B = (2Q_s + M_s) G_s -- go through a small component-major LDS buffer (opb[8][64]: conflict-free writes by column,
-    // conflict-free reads in fragment layout).  The loop is software-pipelined: while the fragments of stage s are in
-    // flight / on the matrix cores, the VALU advances the recursion to stage s+1.
-    // The remaining second-order rows -- row rho = 2s+1 (d_f of stage s): mpd*G_psi + mvd*G_v, mdd on the diagonal -- are
-    // written, scaled by sc, straight into the packed K image by the lane of each column; they define every ODD row of
-    // the image (build_tiles reads them back into the C-layout tiles; nothing else of K goes through LDS).
+    // stage record as the condensing recursions read it (uniform address: one LDS broadcast per field)
     struct Rec { T a02, a03, a12, a13, a23, bx, by, bp, mpp, mpv, mpd, mvd, mdd; };
     DEV void load_rec(Rec &r, int s) const
     {
         const T *q = lin + LSTR * s;  // record N is all zero (linearize)
         r.a02 = q[0]; r.a03 = q[1]; r.a12 = q[2]; r.a13 = q[3]; r.a23 = q[4]; r.bx = q[5]; r.by = q[6]; r.bp = q[7];
         r.mpp = q[8]; r.mpv = q[9]; r.mpd = q[10]; r.mvd = q[11]; r.mdd = q[12];  // zero when the Gauss-Newton matrix is wanted
-    }
-    struct CondState { T gx, gy, gp, gv, fa[NT], fb[NT]; Rec cur; };
-    // Trips [s0, s1) of the stage loop with a FIXED number of live tile rows (ROWS = tile rows that hold columns < 2s), so the body
-    // is one basic block: the products of state s are issued first and run on the matrix cores in the shadow of the recursion work.
-    template <int ROWS> DEV void condense_trips(int s0, int s1, CondState &S, acc_t (&acc)[NTT], T sc)
-    {
-        const int kk = lane >> 4, c = lane & 15;
-        const T pef = (lane & 1) ? (T)1 : (T)0;      // d_f columns take B's steering column, acc columns (0,0,0,dt)
-        const T gvnew = (lane & 1) ? (T)0 : pt[PT_DT];
-        T *colK = Lc + offc_rt(lane < n ? lane : 0);  // column `lane` of the packed K image
-        const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3];
-#pragma unroll 2
-        for (int s = s0; s < s1; ++s) {
-            Rec nxt;
-            load_rec(nxt, s + 1);  // stage records are fetched one trip ahead: no LDS round trip on the recursion's path
-            // odd row rho = 2s+1 of the image from G_s (zero second-order part when !exact)
-            const int rho = 2 * s + 1;
-            const T val = sc * (S.cur.mpd * S.gp + S.cur.mvd * S.gv) + (lane == rho ? sc * S.cur.mdd : (T)0);
-            T *dst = (lane <= rho && lane < n) ? colK + rho : xb + lane;
-            *dst = val;
-            // ---- advance the recursion to state s+1 ---------------------------------------------------------------
-            S.gx += S.cur.a02 * S.gp + S.cur.a03 * S.gv;
-            S.gy += S.cur.a12 * S.gp + S.cur.a13 * S.gv;
-            S.gp += S.cur.a23 * S.gv;
-            // columns 2s, 2s+1 enter with B_s; their G was exactly zero until now, so entering is an FMA with an indicator
-            const bool isnew = (lane >> 1) == s;
-            const T ind = isnew ? pef : (T)0;
-            S.gx = fma(ind, S.cur.bx, S.gx);
-            S.gy = fma(ind, S.cur.by, S.gy);
-            S.gp = fma(ind, S.cur.bp, S.gp);
-            S.gv += isnew ? gvnew : (T)0;
-            // products of state s: its fragments were requested at the end of the previous trip and have landed while the recursion
-            // ran (the empty asm ties the first fragment to a recursion result, so the wait for them is not scheduled at the loop top)
-            if (ROWS > 0) asm volatile("" : "+v"(S.fa[0]), "+v"(S.gx));
-#pragma unroll
-            for (int ti = 0; ti < ROWS; ++ti)
-#pragma unroll
-                for (int tj = 0; tj <= ti; ++tj)
-                    acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(S.fa[ti], S.fb[tj], acc[ti * (ti + 1) / 2 + tj]);
-            // weights of state s+1: 2Q_{s+1} + M_{s+1}^{psi,v}
-            const T Cv1 = s + 1 <= N - 1 ? Cv2 : (T)0;
-            // component-major staging: opb[comp][col]
-            opb[0 * 64 + lane] = S.gx; opb[1 * 64 + lane] = S.gy; opb[2 * 64 + lane] = S.gp; opb[3 * 64 + lane] = S.gv;
-            opb[4 * 64 + lane] = Cx2 * S.gx;
-            opb[5 * 64 + lane] = Cy2 * S.gy;
-            opb[6 * 64 + lane] = (Cp2 + nxt.mpp) * S.gp + nxt.mpv * S.gv;
-            opb[7 * 64 + lane] = Cv1 * S.gv + nxt.mpv * S.gp;
-            WFENCE();
-            // the record fetched at the top of this trip is long complete: take its (free) wait HERE, before the fragment reads are
-            // issued -- otherwise the in-order LDS counter makes the next trip's first use of the record wait for the fragments too
-            pin(nxt.a02); pin(nxt.a03); pin(nxt.a12); pin(nxt.a13); pin(nxt.a23); pin(nxt.bx); pin(nxt.by); pin(nxt.bp);
-            pin(nxt.mpp); pin(nxt.mpv); pin(nxt.mpd); pin(nxt.mvd); pin(nxt.mdd);
-            // fragments of state s+1 (the registers were consumed by the MFMAs at the top)
-#pragma unroll
-            for (int t = 0; t < (ROWS + 1 < NT ? ROWS + 1 : NT); ++t) {  // the next trip has at most one more live tile row
-                S.fa[t] = opb[kk * 64 + 16 * t + c]; S.fb[t] = opb[(4 + kk) * 64 + 16 * t + c];
-            }
-            S.cur = nxt;
-        }
     }
     // The second-order entries of the stage records decide between the exact and the Gauss-Newton matrix: linearize writes them only
     // when the exact Hessian is wanted, and a fallback inside an iteration clears them (drop_second_order).
@@ -673,29 +613,8 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
     }
     DEV void condense(T sc, acc_t (&acc)[NTT])
     {
-        if constexpr (MODEL == 1) { condense_frenet(sc, acc); return; }
-#ifndef KMPC_CONDENSE_MFMA
-        condense_adjoint(sc);
-        return;
-#endif
-#pragma unroll
-        for (int t = 0; t < NTT; ++t) acc[t] = acc_t{0, 0, 0, 0};
-        CondState S;
-        S.gx = S.gy = S.gp = S.gv = (T)0;            // column `lane` of G at the current state
-#pragma unroll
-        for (int t = 0; t < NT; ++t) S.fa[t] = S.fb[t] = (T)0;  // MFMA fragments of the state whose products are still to be issued
-        load_rec(S.cur, 0);
-        // trip s multiplies state s, whose columns 0..2s-1 live in ceil(2s/16) tile rows
-        condense_trips<0>(0, 1, S, acc, sc);
-        condense_trips<1>(1, N < 9 ? N : 9, S, acc, sc);
-        if (NT >= 2 && N > 9) condense_trips<(NT >= 2 ? 2 : 1)>(9, N < 17 ? N : 17, S, acc, sc);
-        if (NT >= 3 && N > 17) condense_trips<(NT >= 3 ? 3 : 1)>(17, N < 25 ? N : 25, S, acc, sc);
-        if (NT >= 4 && N > 25) condense_trips<(NT >= 4 ? 4 : 1)>(25, N, S, acc, sc);
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int tj = 0; tj <= ti; ++tj)
-                acc[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(S.fa[ti], S.fb[tj], acc[ti * (ti + 1) / 2 + tj]);
+        if constexpr (MODEL == 1) condense_frenet(sc, acc);   // dense stage Jacobians: MFMA contraction into `acc`
+        else condense_adjoint(sc);                            // Cartesian model: into the packed image, `acc` untouched
     }
 
     // KKT tiles for the factorisation, built in registers: K = sc*(H + input Hessian) + A^T W A + reg*I in MFMA C-layout tiles (lower
@@ -706,11 +625,7 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
     // entries, which lane j computes together with the input-cost Hessian (MKZMPCPathFollower.jl:99-102) and hands over through
     // a 2 x n staging buffer.  The second-order ODD rows come from the packed image, where condense put them.
     static constexpr int NTF = (n + 1 + 15) / 16, NTTF = NTF * (NTF + 1) / 2;
-#ifdef KMPC_CONDENSE_MFMA
-    static constexpr bool ADJ = false;
-#else
     static constexpr bool ADJ = MODEL == 0;  // the whole lower triangle of sc*H is in the packed image (condense_adjoint), nothing in kt
-#endif
     // In place: on entry the first NTT tiles of kt are the accumulators of condense (same packed lower-triangular tile order).
     DEV void build_tiles(T sc, T reg, acc_t (&kt)[NTTF])
     {
@@ -1363,7 +1278,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void km
     sv.solve(io, b);
 }
 
-// diagnostics (tests/test_gpu_kernels.py): the KKT pipeline of THIS kernel -- roll-out, costates, MFMA condensing, in-register KKT
+// diagnostics (tests/test_gpu_kernels.py): the KKT pipeline of THIS kernel -- roll-out, costates, condensing, in-register KKT
 // assembly, blocked Cholesky, block substitutions -- at a given point, form weights, scaling and shift
 template <typename T, int N>
 __global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void kmpc_fast_kkt_kernel(KP P, KDbgK<T> io)

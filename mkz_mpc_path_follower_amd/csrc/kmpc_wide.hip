@@ -7,15 +7,16 @@
 //   * the 28 tiles live in REGISTERS, spread over the four waves of a workgroup by tile ROW: wave w owns rows 6-w and w-1
 //     (7 tiles = 56 VGPRs each).  Every loop over tiles has compile-time tile COLUMNS and a wave-uniform (SGPR) tile row, so all
 //     waves run the same code;
-//   * LDS holds only what crosses waves: the packed block-LDL^T factor L~ (n(n+3)/2 words, 41 KB), the double-buffered MFMA
-//     fragment staging of the condensing recursion, the double-buffered 4-column Cholesky panel, the stage records and a few
-//     n-vectors: 73 KB -> two workgroups (8 waves) per CU, 2 waves per SIMD, 256 VGPRs;
+//   * LDS holds only what crosses waves: the packed image of sc*H / the block-LDL^T factor L~ (n(n+3)/2 words, 41 KB), the
+//     double-buffered 4-column Cholesky panel, the stage records, the terminal sensitivities and a few n-vectors: 72 KB -> two
+//     workgroups (8 waves) per CU, 2 waves per SIMD, 256 VGPRs;
+//   * condensing in O(N^2): thread j < n carries column j of the Hessian through the adjoint recursion of kmpc_fast.hip (no
+//     barrier inside, no matrix product); the matrix cores do the trailing updates of the factorisation;
 //   * one thread per linear form (nf = 5N-2 = 248 <= 256) and per input (n = 100): every elementwise pass of the interior-point
 //     method is ONE instruction stream of NF = 1; stage vectors (roll-out, costates) are evaluated redundantly by every wave
 //     (lane k = stage k), so their results need no exchange;
-//   * workgroup barriers only where data crosses waves: one per condensing stage, one per Cholesky block-step, one per
-//     reduction; the three triangular substitutions run in wave 0 with two slots per lane (v_readlane broadcasts, no barrier
-//     inside).
+//   * workgroup barriers only where data crosses waves: one per Cholesky block-step, one per reduction; the three triangular
+//     substitutions run in wave 0 with two slots per lane (v_readlane broadcasts, no barrier inside).
 #include "kmpc_math.h"
 
 #define WGSYNC() __syncthreads()
@@ -42,7 +43,7 @@ template <typename T, int N> struct WideSolver {
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
     // LDS map (elements of T)
-    static constexpr int O_LC = 0, O_OPB = (LC + 1) & ~1, O_LIN = O_OPB + 2 * 8 * NP, O_XB = O_LIN + WLIN * (N + 1), O_WB = O_XB + 128,
+    static constexpr int O_LC = 0, O_OPB = (LC + 1) & ~1, O_LIN = O_OPB + 2 * 4 * NP + 256 + 3 * 128, O_XB = O_LIN + WLIN * (N + 1), O_WB = O_XB + 128,
                          O_CBW = O_WB + 256, O_RED = O_CBW + 4 * 64, O_SINV = O_RED + 2 * 32, O_X2 = O_SINV + 16 * NB, O_X3 = O_X2 + 128,
                          O_GB = O_X3 + 128, O_UB = O_GB + 128, O_CS = O_UB + 128, O_PT = O_CS + 4 * 16, O_KC = O_PT + 32, O_END = O_KC + (sizeof(T) == 8 ? KC_COUNT : 0);
     static constexpr int lds_elems() { return O_END; }
@@ -68,10 +69,9 @@ template <typename T, int N> struct WideSolver {
         cb = base + O_CBW + 64 * wv;  // every wave keeps its OWN copy of the stage prefix / suffix sums: no barrier to share them
         red = base + O_RED; sinvb = base + O_SINV; x2 = base + O_X2; x3 = base + O_X3; gbl = base + O_GB; ubl = base + O_UB;
         cs = base + O_CS + 16 * wv;    // wave-uniform scalars that are read once or twice per iteration: every wave parks its own copy
-        pan = opb;                      // the Cholesky panel (2 x 4 NP) and the 2 x n staging of build_tiles alias the condensing
-        dgs = opb + 2 * 4 * NP; sbs = dgs + 128;  // staging buffer: the three are live one after the other
+        pan = opb;                      // the double-buffered Cholesky panel (2 x 4 NP)
+        dgs = opb + 2 * 4 * NP; sbs = dgs + 128;  // 2 x n staging of build_tiles
         gnb = sbs + 128;                // terminal sensitivities G_N [3][128], written by linearize, read by every condense of that linearisation
-        static_assert(2 * 4 * NP + 256 + 3 * 128 <= 2 * 8 * NP, "panel, build staging and the G_N table fit the buffer");
         for (int e = tid; e < 16 * NB; e += 256) sinvb[e] = (T)0;
         kc.tab = base + O_KC;
         if (sizeof(T) == 8 && tid < KC_COUNT) const_cast<T *>(kc.tab)[tid] = (T)kmpc_coef[tid];
@@ -306,11 +306,7 @@ template <typename T, int N> struct WideSolver {
         WGSYNC();
     }
 
-    // ---- condensing on the matrix cores ----------------------------------------------------------------------------------------
-    // H = sum_s G_s^T (2 Q_s + M_s) G_s accumulates in the tiles of this wave's two tile rows (k0: row R0, k1: row R1; unscaled).
-    // Threads 0..NP-1 (waves 0 and 1) carry the sensitivity recursion, one column each, and stage the MFMA fragments of every
-    // state -- A = G_s, B = (2Q_s + M_s) G_s -- component-major in LDS (double-buffered: one barrier per stage); every wave
-    // then multiplies its tile rows.  The second-order ODD rows go, scaled, straight into the packed image (see kmpc_fast.hip).
+    // ---- condensing ----------------------------------------------------------------------------------------------------------------------
     struct Rec { T a02, a03, a12, a13, a23, bx, by, bp, mpp, mpv, mpd, mvd, mdd; };
     DEV void load_rec(Rec &r, int s) const
     {
@@ -356,86 +352,6 @@ template <typename T, int N> struct WideSolver {
     // Tile rows of wave W (compile-time in everything below: each wave runs its own specialisation, selected once per
     // factorisation by a switch on the wave number; tile indices, liveness tests and register arrays are then all static)
     template <int W> struct Rows { static constexpr int R0 = NTF - 1 - W, R1 = W - 1, N0 = R0 + 1, N1 = R1 >= 0 ? R1 + 1 : 1; };
-    template <int W> DEV void condense(T sc, acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
-    {
-        constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1, N0 = Rows<W>::N0, N1 = Rows<W>::N1;
-        const int kk = lane >> 4, c = lane & 15;
-#pragma unroll
-        for (int t = 0; t < N0; ++t) k0[t] = acc_t{0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < N1; ++t) k1[t] = acc_t{0, 0, 0, 0};
-        const bool colthr = tid < NP;               // this thread carries column `tid` of G
-        const int col = tid;
-        T gx = 0, gy = 0, gp = 0, gv = 0;
-        const T pef = (col & 1) ? (T)1 : (T)0;       // d_f columns take B's steering column, acc columns (0,0,0,dt)
-        const T gvnew = (col & 1) ? (T)0 : pt[PT_DT];
-        T *colK = Lc + offc_rt(col < n ? col : 0);
-        const T Cx2 = cwt[0], Cy2 = cwt[1], Cp2 = cwt[2], Cv2 = cwt[3];
-        T fa0 = 0, fa1 = 0, fb[N0];
-#pragma unroll
-        for (int t = 0; t < N0; ++t) fb[t] = (T)0;
-#pragma nounroll
-        for (int s = 0; s < N; ++s) {
-            if (colthr) {
-                Rec cur;
-                load_rec(cur, s);
-                const T *qn = lin + WLIN * (s + 1);   // record N is all zero (linearize)
-                const T nmpp = qn[8], nmpv = qn[9];
-                // odd row rho = 2s+1 of the image from G_s (zero second-order part when the Gauss-Newton matrix is wanted)
-                const int rho = 2 * s + 1;
-                const T val = sc * (cur.mpd * gp + cur.mvd * gv) + (col == rho ? sc * cur.mdd : (T)0);
-                if (col <= rho && col < n) colK[rho] = val;
-                // advance the recursion to state s+1
-                gx += cur.a02 * gp + cur.a03 * gv;
-                gy += cur.a12 * gp + cur.a13 * gv;
-                gp += cur.a23 * gv;
-                const bool isnew = (col >> 1) == s;
-                const T ind = isnew ? pef : (T)0;
-                gx = fma(ind, cur.bx, gx);
-                gy = fma(ind, cur.by, gy);
-                gp = fma(ind, cur.bp, gp);
-                gv += isnew ? gvnew : (T)0;
-                const T Cv1 = s + 1 <= N - 1 ? Cv2 : (T)0;
-                T *o = opb + ((s + 1) & 1) * 8 * NP + col;
-                o[0 * NP] = gx; o[1 * NP] = gy; o[2 * NP] = gp; o[3 * NP] = gv;
-                o[4 * NP] = Cx2 * gx;
-                o[5 * NP] = Cy2 * gy;
-                o[6 * NP] = (Cp2 + nmpp) * gp + nmpv * gv;
-                o[7 * NP] = Cv1 * gv + nmpv * gp;
-            }
-            // products of state s (state 0 is identically zero): its fragments were requested after the previous barrier and have
-            // landed while the recursion ran; nothing in the trip waits for the matrix cores
-            mfma_state<W>(s, fa0, fa1, fb, k0, k1);
-            WGSYNC();
-            // fragments of state s+1: columns < 2(s+1) are non-zero
-            {
-                const T *o = opb + ((s + 1) & 1) * 8 * NP;
-                const int cols = 2 * (s + 1);
-                const bool l0 = 16 * R0 < cols, l1 = R1 >= 0 && 16 * R1 < cols;
-                const int tmax = l0 ? R0 : (l1 ? R1 : -1);
-                if (l0) fa0 = o[kk * NP + 16 * R0 + c];
-                if (l1) fa1 = o[kk * NP + 16 * R1 + c];
-#pragma unroll
-                for (int t = 0; t < N0; ++t)
-                    if (t <= tmax) fb[t] = o[(4 + kk) * NP + 16 * t + c];
-            }
-        }
-        mfma_state<W>(N, fa0, fa1, fb, k0, k1);
-    }
-    template <int W> DEV void mfma_state(int s, T fa0, T fa1, const T (&fb)[Rows<W>::N0], acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
-    {
-        constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
-        const int cols = 2 * s;
-        if (16 * R0 < cols) {
-#pragma unroll
-            for (int t = 0; t <= R0; ++t) k0[t] = Real<T>::mfma(fa0, fb[t], k0[t]);
-        }
-        if (R1 >= 0 && 16 * R1 < cols) {
-#pragma unroll
-            for (int t = 0; t <= R1; ++t) k1[t] = Real<T>::mfma(fa1, fb[t], k1[t]);
-        }
-    }
-
     // ---- KKT tiles, in place: K = sc*(H + input Hessian) + A^T W A + reg*I, rhs -sc*g as row n ------------------------------------
     // (needs stage_form_weights(w) done: wb = form weights, cb = suffix sums of the speed weights)
     template <int NTL> DEV void build_row(T sc, int ti, acc_t (&kt)[NTL])

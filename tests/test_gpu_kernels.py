@@ -78,7 +78,7 @@ def _forms_matrix(N, dt=0.2):
 @pytest.mark.parametrize("hessian", [0, 1])
 def test_kkt_pipeline_of_the_solve_kernels(oracle, N, dtype, hessian):
     """The code BENCH times, block by block (kmpc_debug_kkt dispatches the same FastSolver / WideSolver members the solve uses):
-    condensing on the matrix cores + in-register KKT assembly == sc*H + A^T W A + reg*I built from the oracle's Hessian in numpy;
+    condensing (adjoint recursion in the compile-time-horizon kernels, matrix cores in the generic one) + in-register KKT assembly == sc*H + A^T W A + reg*I built from the oracle's Hessian in numpy;
     blocked Cholesky + block-LDL^T substitutions == numpy's solve of that system.
     fp64: |K - K_ref| <= 1e-10 max|K|, gradient 1e-9, solve residual <= 1e-9 |rhs|;  fp32: 2e-5 / 1e-4 / 2e-3."""
     O = oracle
