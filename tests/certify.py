@@ -110,3 +110,30 @@ def stratified_sample(iters, status, n, seed=0):
             break
         pick.add(int(i))
     return np.array(sorted(pick))
+
+
+def second_order_check(O, p, q, U, act_tol=1e-6, h=1e-5):
+    """Second-order NECESSARY condition of a local minimum at U: the Hessian of the state-eliminated objective (every constraint of the
+    condensed program is linear in U, so it is the Lagrangian Hessian) is positive semi-definite on the null space of the active rows.
+    The Hessian is a central finite difference of oracle/kmpc_nlp.c's costate gradient -- independent of the condensing code of
+    oracle/kmpc_condensed.c and of the kernels.  Returns (smallest eigenvalue of Z^T H Z divided by max(1, max |H|), dim Z)."""
+    U = np.asarray(U, dtype=np.float64).reshape(-1)
+    n = len(U)
+    A, b = O.ineq(p, q, relax=1e-8)
+    act = (b - A @ U) <= act_tol * np.maximum(1.0, np.abs(b))
+    H = np.empty((n, n))
+    for j in range(n):
+        e = np.zeros(n)
+        e[j] = h
+        H[:, j] = (O.grad(p, q, U + e) - O.grad(p, q, U - e)) / (2.0 * h)
+    H = 0.5 * (H + H.T)
+    if act.any():
+        _, sv, Vt = np.linalg.svd(A[act], full_matrices=True)
+        rank = int((sv > 1e-10 * max(1.0, sv.max())).sum())
+        Z = Vt[rank:].T
+    else:
+        Z = np.eye(n)
+    if Z.shape[1] == 0:
+        return 0.0, 0
+    ev = np.linalg.eigvalsh(Z.T @ H @ Z)
+    return float(ev.min() / max(1.0, np.abs(H).max())), int(Z.shape[1])

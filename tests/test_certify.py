@@ -85,6 +85,30 @@ def test_zero_start_fixture_is_what_the_oracle_computes(oracle, N):
             _assert_certified(CT.certify_batch(O, p, d, U, idx=np.where(other)[0]), 1e-6 if N < 50 else 1e-5, 1e-8 + 1e-12, "zero-start N=%d" % N)
 
 
+def test_second_order_condition_of_the_fixture_minima_and_of_a_non_minimum(oracle):
+    """KKT points of a non-convex program may be saddles.  Both minima of the zero-start fixture problems whose two solvers disagree satisfy
+    the second-order necessary condition (Hessian by finite differences of the costate gradient, positive semi-definite on the null space of
+    the active rows); the check does see negative curvature where there is some: at the feed-forward-like interior point 0.5 U* of a car
+    that is too fast for its reference the unconstrained Hessian is indefinite."""
+    O = oracle
+    G = np.load(os.path.join(GOLD, "kmpc_zero_start_N20.npz"))
+    p = O.params(20, tuple(G["weights"]))
+    rel = np.abs(G["J_ipopt_like"] - G["J_condensed"]) / np.maximum(1.0, np.abs(G["J_ipopt_like"]))
+    idx = list(np.where(rel > 1e-6)[0]) + list(range(8))
+    for i in idx:
+        q = O.problem(p, G["z0"][i], G["ref"][i], G["v_target"][i], G["u_prev"][i])
+        for U in (G["U_condensed"][i], G["U_ipopt_like"][i]):
+            ev, dz = CT.second_order_check(O, p, q, U)
+            assert ev >= -1e-6, (i, ev, dz)
+    d = make_batch(4096, 20, cfg_id=2)
+    b = 1693   # the bench batch's slowest problem: 2.7 m/s faster than its reference, solved through inertia shifts
+    q = O.problem(O.params(20), d["z0"][b], d["ref"][b], d["v_target"][b], d["u_prev"][b])
+    r = O.solve_condensed(O.params(20), q)
+    assert r["status"] == 0 and CT.second_order_check(O, O.params(20), q, r["U"])[0] >= -1e-6
+    ev_free, dz = CT.second_order_check(O, O.params(20), q, 0.5 * r["U"].ravel(), act_tol=-1.0)
+    assert dz == 40 and ev_free < -1e-4, ev_free
+
+
 # ------------------------------------------------------------------------------------------------ GPU: BASELINE config sizes
 def _gpu_solve(N, d, dtype, **kw):
     import torch
@@ -127,6 +151,26 @@ def test_certify_config3_B262144_N20_fp32(oracle):
     r64 = _gpu_solve(N, d, torch.float64)
     rel = np.abs(r["cost"] - r64["cost"]) / np.maximum(1.0, np.abs(r64["cost"]))
     assert (rel <= 1e-3).mean() >= 0.9999, (rel > 1e-3).sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,cfg", [(20, 2), (50, 5)])
+def test_gpu_solutions_satisfy_the_second_order_condition(oracle, N, cfg):
+    """the returned points are local MINIMA, not just KKT points: second-order necessary condition on the problems with the most iterations
+    (the non-convex ones, solved through inertia shifts) and a uniform sample of the config's batch"""
+    import torch
+    B = 4096
+    d = make_batch(B, N, cfg_id=cfg)
+    r = _gpu_solve(N, d, torch.float64)
+    idx = CT.stratified_sample(r["iters"], r["status"], 192 if N == 20 else 48)
+    p = oracle.params(N)
+    worst = np.inf
+    for i in idx:
+        q = oracle.problem(p, d["z0"][i], d["ref"][i], d["v_target"][i], d["u_prev"][i])
+        ev, dz = CT.second_order_check(oracle, p, q, r["U"][i])
+        worst = min(worst, ev)
+        assert ev >= -1e-6, (int(i), ev, dz, int(r["iters"][i]))
+    print("N=%d: smallest reduced-Hessian eigenvalue / max|H| over %d problems: %.2e" % (N, len(idx), worst))
 
 
 @pytest.mark.gpu
