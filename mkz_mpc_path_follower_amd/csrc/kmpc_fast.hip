@@ -1262,9 +1262,11 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
 // waves per SIMD: the fp64 kernel needs ~250 VGPRs to run without scratch spills (measured: at 128 VGPRs the
 // spills moved 1.6 GB of HBM traffic per 4096-problem launch against 2.4 MB of algorithmic bytes); the kernel is
 // issue-bound, not occupancy-bound, so 2 waves/SIMD without spills beats 4 with.  fp32 fits 4 waves spill-free up to N = 20 (128 VGPRs; +10 % over 3
-// waves at N = 16 / 20) and 3 waves beyond.
+// waves at N = 16 / 20) and 3 waves beyond.  fp64 at N <= 12: the LDS footprint (10.9 / 13.1 KB) admits 12 waves per CU and a wave issues at most
+// one vector instruction per 6.5 cycles (tools/calib/issue_probe.hip), so a third wave per SIMD is worth the 36 / 60 B of scratch that 168
+// VGPRs cost: +21 % / +16 % at B = 262 144, +7 % / +3 % at B = 4096.  From N = 16 the LDS footprint allows 9 waves per CU or fewer.
 template <typename T, int N>
-__global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N <= 12 ? 3 : 2) : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N>::lds_elems() * sizeof(T)];
     if ((int)blockIdx.x >= P.B) return;
