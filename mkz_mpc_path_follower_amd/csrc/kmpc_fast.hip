@@ -1265,8 +1265,9 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
 // waves at N = 16 / 20) and 3 waves beyond.  fp64 at N <= 12: the LDS footprint (10.9 / 13.1 KB) admits 12 waves per CU and a wave issues at most
 // one vector instruction per 6.5 cycles (tools/calib/issue_probe.hip), so a third wave per SIMD is worth the 36 / 60 B of scratch that 168
 // VGPRs cost: +21 % / +16 % at B = 262 144, +7 % / +3 % at B = 4096.  From N = 16 the LDS footprint allows 9 waves per CU or fewer.
+// fp32 at N <= 12 likewise takes a fifth wave (96 VGPRs, 0 / 8 B of scratch): +7 % / +6 % at B = 262 144.
 template <typename T, int N>
-__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N <= 12 ? 3 : 2) : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N <= 12 ? 3 : 2) : (N <= 12 ? 5 : (N <= 20 ? 4 : 3))) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N>::lds_elems() * sizeof(T)];
     if ((int)blockIdx.x >= P.B) return;
