@@ -1355,7 +1355,7 @@ static hipError_t launch_fast_n(const KP &P, const KIO<T> &io, hipStream_t st)
 // Frenet-frame functor (kmpc_config.model = 1): io.ref carries k_poly [B,4]  (fp64 at N = 28: 34.5 KB of LDS per wave leave one wave per
 // SIMD anyway, so the bound says so and the allocator may use all 512 registers)
 template <typename T, int N>
-__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N >= 28 ? 1 : 2) : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_frenet_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N >= 28 ? 1 : (N <= 8 ? 3 : 2)) : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_frenet_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N, 1>::lds_elems() * sizeof(T)];
     if ((int)blockIdx.x >= P.B) return;
