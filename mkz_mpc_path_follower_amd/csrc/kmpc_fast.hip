@@ -1266,8 +1266,9 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
 // one vector instruction per 6.5 cycles (tools/calib/issue_probe.hip), so a third wave per SIMD is worth the 36 / 60 B of scratch that 168
 // VGPRs cost: +21 % / +16 % at B = 262 144, +7 % / +3 % at B = 4096.  From N = 16 the LDS footprint allows 9 waves per CU or fewer.
 // fp32 at N <= 12 likewise takes a fifth wave (96 VGPRs, 0 / 8 B of scratch): +7 % / +6 % at B = 262 144.
-template <typename T, int N>
-__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N <= 12 ? 3 : 2) : (N <= 12 ? 5 : (N <= 20 ? 4 : 3))) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
+// The spills cost single-wave latency (N = 8 closed loop, B = 1: 80 -> 86 us p50), so the denser build (kmpc_solve_fast_dense_kernel) is
+// launched only for batches that fill the chip (B > 2048); small batches and the B = 1 latency path keep the spill-free build.
+template <typename T, int N> DEV void kmpc_solve_fast_body(const KP &P, const KIO<T> &io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N>::lds_elems() * sizeof(T)];
     if ((int)blockIdx.x >= P.B) return;
@@ -1279,6 +1280,17 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? (N <= 12 ? 3 : 2) : (N <= 12 ?
     FastSolver<T, N> sv(P, smem);
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
     sv.solve(io, b);
+}
+template <typename T, int N>
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
+{
+    kmpc_solve_fast_body<T, N>(P, io);
+}
+// the same solve at one more wave per SIMD (N <= 12, batches that fill the chip)
+template <typename T, int N>
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? 3 : 5) void kmpc_solve_fast_dense_kernel(KP P, KIO<T> io)
+{
+    kmpc_solve_fast_body<T, N>(P, io);
 }
 
 // diagnostics (tests/test_gpu_kernels.py): the KKT pipeline of THIS kernel -- roll-out, costates, condensing, in-register KKT
@@ -1348,6 +1360,12 @@ template hipError_t kmpc_launch_fast_kkt<float>(const KP &, const KDbgK<float> &
 template <typename T, int N>
 static hipError_t launch_fast_n(const KP &P, const KIO<T> &io, hipStream_t st)
 {
+    if constexpr (N <= 12) {
+        if (P.B > 2048) {
+            hipLaunchKernelGGL((kmpc_solve_fast_dense_kernel<T, N>), dim3(P.B), dim3(64), 0, st, P, io);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((kmpc_solve_fast_kernel<T, N>), dim3(P.B), dim3(64), 0, st, P, io);
     return hipGetLastError();
 }

@@ -279,6 +279,20 @@ def test_start_order_does_not_change_results():
         assert (a["status"] == 0).all()
 
 
+@pytest.mark.parametrize("N", [8, 12])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_dense_build_of_the_short_horizons_changes_nothing(N, dtype):
+    """N <= 12 has two builds of the same solve (csrc/kmpc_fast.hip): one more wave per SIMD for batches above 2048 problems, the spill-free
+    one below.  Same source, same arithmetic: the first 2048 problems of a 4096-problem launch and those 2048 problems launched alone
+    agree bit for bit."""
+    d = make_batch(4096, N, cfg_id=2, dtype=np.float64 if dtype == torch.float64 else np.float32)
+    a = _solve(N, d, dtype=dtype)
+    b = _solve(N, {k: v[:2048] for k, v in d.items()}, dtype=dtype)
+    for k in ("status", "iters", "cost", "viol", "u0", "U", "X"):
+        assert np.array_equal(a[k][:2048], b[k]), k
+    assert (a["status"] == 0).all()
+
+
 def test_infeasible_and_edge_inputs():
     """Q5: v0 outside [0, 20] -> status Infeasible, outputs finite and inside the input box."""
     N = 8
