@@ -1012,23 +1012,22 @@ __global__ __launch_bounds__(256, 2) void kmpc_wide_kkt_kernel(KP P, KDbgK<T> io
 }
 template <typename T> hipError_t kmpc_launch_wide_kkt(const KP &P, const KDbgK<T> &io, hipStream_t st)
 {
-    if (P.N == 50) {
-        hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
-        return hipGetLastError();
-    }
-    return hipErrorInvalidValue;
+    if (P.N == 50) hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
+    else if (P.N == 48) hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 48>), dim3(P.B), dim3(256), 0, st, P, io);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 template hipError_t kmpc_launch_wide_kkt<double>(const KP &, const KDbgK<double> &, hipStream_t);
 template hipError_t kmpc_launch_wide_kkt<float>(const KP &, const KDbgK<float> &, hipStream_t);
 
-template <typename T> bool kmpc_wide_available(int N) { return N == 50; }
+// horizons whose n + 1 rows make 7 tile rows with one thread per form (5N - 2 <= 256) and 4-column panels: N = 48 and the BASELINE's N = 50
+template <typename T> bool kmpc_wide_available(int N) { return N == 50 || N == 48; }
 template <typename T> hipError_t kmpc_launch_solve_wide(const KP &P, const KIO<T> &io, hipStream_t st)
 {
-    if (P.N == 50) {
-        hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
-        return hipGetLastError();
-    }
-    return hipErrorInvalidValue;
+    if (P.N == 50) hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
+    else if (P.N == 48) hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 48>), dim3(P.B), dim3(256), 0, st, P, io);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 template bool kmpc_wide_available<double>(int);
 template bool kmpc_wide_available<float>(int);

@@ -1,11 +1,11 @@
-"""N = 50: four-wave kernel (kernel_variant 0) vs the generic one-wave kernel (1) and the CPU oracle; timing at B = 4096"""
+"""N = 50 (WN=48 for the other compiled horizon): four-wave kernel (kernel_variant 0) vs the generic one-wave kernel (1) and the CPU oracle; timing at B = 4096"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mkz_mpc_path_follower_amd import BatchMPC
 from mkz_mpc_path_follower_amd.synthetic import make_batch
-N = 50
+N = int(os.environ.get("WN", "50"))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 d = make_batch(B, N, cfg_id=5)
 out = {}
