@@ -150,7 +150,7 @@ int32_t kmpc_debug_condense(kmpc_handle *h, int32_t B, const void *z0, const voi
                             const void *v_target, const void *U, int32_t hessian, void *H, void *g,
                             void *J, void *stream);
 /* The KKT pipeline of the kernel kmpc_solve_batch runs for this handle's horizon (compile-time-horizon kernels only: N = 8, 12, ..., 28
- * one wave per problem; N = 40, 44, 48 and 50 four waves): at inputs U [B,N,2], two-sided form weights w [B,5N-2] (>= 0; order: 2N input boxes,
+ * one wave per problem; N = 32, 36, ..., 48 and 50 four waves): at inputs U [B,N,2], two-sided form weights w [B,5N-2] (>= 0; order: 2N input boxes,
  * 2(N-1) rate forms, N speed forms), objective scaling sc > 0 and shift reg >= 0 it assembles
  *     K = sc * H(U) + A^T diag(w) A + reg * I      (H: exact condensed Hessian if hessian = 1, Gauss-Newton if 0)
  * on the matrix cores, factors it (blocked Cholesky) and solves once through the block substitutions:

@@ -1,5 +1,5 @@
 // kmpc_wide.hip -- long-horizon solver kernel for gfx950: ONE WORKGROUP OF FOUR WAVES PER PROBLEM (BASELINE config 5, N = 50; also
-// instantiated for N = 48 and, with six tile rows instead of seven, N = 44 and 40).
+// instantiated for N = 48 and, with six / five tile rows instead of seven, N = 44, 40 / 36, 32).
 //
 // Same algorithm and same results as the one-wave kernels (kmpc_fast.hip / kmpc_kernels.hip; reference NLP:
 // scripts/mpc_utils/MKZMPCPathFollower.jl:65-123).  At N = 50 the condensed KKT matrix has n = 100 columns (+ the rhs row): 28
@@ -38,7 +38,7 @@ template <typename T, int N> struct WideSolver {
     static constexpr int SROWS = (N + 1 + 15) / 16;  // 16-lane rows that carry stage data
     static constexpr int LC = n * (n + 3) / 2;       // packed lower triangle + rhs row, column-major
     static constexpr int NB = n / 4;                 // 4-column block-steps
-    static_assert(NTF == 7 || NTF == 6, "tile rows are dealt to the four waves as (6), (5,0), (4,1), (3,2) -- or (5), (4,0), (3,1), (2) with six");
+    static_assert(NTF >= 5 && NTF <= 7, "tile rows are dealt to the four waves as (6), (5,0), (4,1), (3,2) -- (5), (4,0), (3,1), (2) with six, (4), (3,0), (2), (1) with five");
     static_assert(nf <= 256 && n % 4 == 0 && N + 1 <= 64, "one thread per form, 4-column panels, one lane per stage");
     typedef typename Real<T>::acc_t acc_t;
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }
@@ -352,8 +352,8 @@ template <typename T, int N> struct WideSolver {
     }
     // Tile rows of wave W (compile-time in everything below: each wave runs its own specialisation, selected once per
     // factorisation by a switch on the wave number; tile indices, liveness tests and register arrays are then all static)
-    template <int W> struct Rows {   // wave W owns tile row NTF-1-W and, while that is still a different row, tile row W-1
-        static constexpr int R0 = NTF - 1 - W, R1 = (W - 1 < R0) ? W - 1 : -1, N0 = R0 + 1, N1 = R1 >= 0 ? R1 + 1 : 1;
+    template <int W> struct Rows {   // wave W owns tile row NTF-1-W and, of the rows 0 .. NTF-5 that are nobody's first row, row W-1
+        static constexpr int R0 = NTF - 1 - W, R1 = (W - 1 < NTF - 4) ? W - 1 : -1, N0 = R0 + 1, N1 = R1 >= 0 ? R1 + 1 : 1;
     };
     // ---- KKT tiles, in place: K = sc*(H + input Hessian) + A^T W A + reg*I, rhs -sc*g as row n ------------------------------------
     // (needs stage_form_weights(w) done: wb = form weights, cb = suffix sums of the speed weights)
@@ -1019,20 +1019,24 @@ template <typename T> hipError_t kmpc_launch_wide_kkt(const KP &P, const KDbgK<T
     else if (P.N == 48) hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 48>), dim3(P.B), dim3(256), 0, st, P, io);
     else if (P.N == 44) hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 44>), dim3(P.B), dim3(256), 0, st, P, io);
     else if (P.N == 40) hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 40>), dim3(P.B), dim3(256), 0, st, P, io);
+    else if (P.N == 36) hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 36>), dim3(P.B), dim3(256), 0, st, P, io);
+    else if (P.N == 32) hipLaunchKernelGGL((kmpc_wide_kkt_kernel<T, 32>), dim3(P.B), dim3(256), 0, st, P, io);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 template hipError_t kmpc_launch_wide_kkt<double>(const KP &, const KDbgK<double> &, hipStream_t);
 template hipError_t kmpc_launch_wide_kkt<float>(const KP &, const KDbgK<float> &, hipStream_t);
 
-// horizons whose n + 1 rows make 7 (N = 48, the BASELINE's 50) or 6 (N = 40, 44) tile rows, with one thread per form (5N - 2 <= 256)
-template <typename T> bool kmpc_wide_available(int N) { return N == 50 || N == 48 || N == 44 || N == 40; }
+// horizons whose n + 1 rows make 7 (N = 48, the BASELINE's 50), 6 (N = 40, 44) or 5 (N = 32, 36) tile rows, with one thread per form (5N - 2 <= 256)
+template <typename T> bool kmpc_wide_available(int N) { return N == 50 || N == 48 || N == 44 || N == 40 || N == 36 || N == 32; }
 template <typename T> hipError_t kmpc_launch_solve_wide(const KP &P, const KIO<T> &io, hipStream_t st)
 {
     if (P.N == 50) hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 50>), dim3(P.B), dim3(256), 0, st, P, io);
     else if (P.N == 48) hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 48>), dim3(P.B), dim3(256), 0, st, P, io);
     else if (P.N == 44) hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 44>), dim3(P.B), dim3(256), 0, st, P, io);
     else if (P.N == 40) hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 40>), dim3(P.B), dim3(256), 0, st, P, io);
+    else if (P.N == 36) hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 36>), dim3(P.B), dim3(256), 0, st, P, io);
+    else if (P.N == 32) hipLaunchKernelGGL((kmpc_solve_wide_kernel<T, 32>), dim3(P.B), dim3(256), 0, st, P, io);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -73,7 +73,7 @@ def _forms_matrix(N, dt=0.2):
     return A
 
 
-@pytest.mark.parametrize("N,dtype", [(8, torch.float64), (20, torch.float64), (28, torch.float64), (50, torch.float64), (48, torch.float64), (44, torch.float64), (40, torch.float32),
+@pytest.mark.parametrize("N,dtype", [(8, torch.float64), (20, torch.float64), (28, torch.float64), (50, torch.float64), (48, torch.float64), (44, torch.float64), (40, torch.float32), (36, torch.float64), (32, torch.float32),
                                      (8, torch.float32), (20, torch.float32), (28, torch.float32)])
 @pytest.mark.parametrize("hessian", [0, 1])
 def test_kkt_pipeline_of_the_solve_kernels(oracle, N, dtype, hessian):
