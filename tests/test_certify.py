@@ -191,6 +191,20 @@ def test_certify_config4_shard_B262144_N20_fp64(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [32, 36, 40, 44, 48])
+def test_certify_four_wave_horizons(oracle, N):
+    """the four-wave kernel is instantiated for N = 32, 36, ..., 48 besides BASELINE's 50 (five, six and seven tile rows): 512 config-5-style
+    problems each, certified with the N = 50 tolerances"""
+    import torch
+    B = 512
+    d = make_batch(B, N, cfg_id=5)
+    r = _gpu_solve(N, d, torch.float64)
+    assert (r["status"] == 0).all(), np.bincount(r["status"])
+    c = CT.certify_batch(oracle, oracle.params(N), d, r["U"])
+    _assert_certified(c, 1e-5, 1e-8 + 1e-12, "N = %d" % N, ref_tol=2e-7)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N", [12, 16, 24, 28])
 def test_certify_other_compiled_horizons(oracle, N):
     """the compile-time-horizon kernel exists for N = 8, 12, ..., 28: the horizons between the BASELINE configs, 2560 bench-style problems each"""
