@@ -12,7 +12,7 @@ from mkz_mpc_path_follower_amd.synthetic import make_batch
 from test_frenet import _cases
 bad = 0
 for dt in (torch.float64, torch.float32):
-    for N in (8, 12, 16, 20, 24, 28, 50):
+    for N in (8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 50):
         d = make_batch(512, N, cfg_id=2)
         o = BatchMPC(N=N, dtype=dt).solve(d["z0"], d["ref"], d["v_target"], d["u_prev"]); torch.cuda.synchronize()
         nb = int((o["status"] != 0).sum()); bad += nb
