@@ -162,6 +162,41 @@ def closed_loop_latency(device, steps=150):
             "worst_status": worst}
 
 
+def closed_loop_fleet(device, B=4096, steps=40):
+    """The same 10 Hz loop for a FLEET: B vehicles spread along the recorded path, each with its own warm start -- waypoint look-ahead, the N = 8
+    solve (the reference's horizon) and the plant, all on the device.  Extra key: vehicle control steps per second and the solve's share."""
+    from mkz_mpc_path_follower_amd.ref_traj import GPSRefTrajectory
+    from mkz_mpc_path_follower_amd.vehicle_sim import VehicleSimulator
+    from mkz_mpc_path_follower_amd.closed_loop import ClosedLoop
+    f = os.path.join(ROOT, "tests", "golden", "path1_decimated.npz")
+    if not os.path.exists(f):
+        return None
+    d = np.load(f)
+    grt = GPSRefTrajectory(arrays=dict(t=d["t"], lat=d["lat"], lon=d["lon"], psi=d["psi"]), traj_horizon=8, traj_dt=0.2, device=device)
+    tr = grt.get_global_trajectory_reference()
+    idx = np.linspace(0, int(0.6 * (len(tr) - 1)), B).astype(int)     # start poses along the first 60 % of the path
+    rng = np.random.default_rng(20180620)
+    off = rng.normal(0.0, 0.3, B)                                      # lateral offsets
+    X0 = tr[idx, 4] - off * np.sin(tr[idx, 3]); Y0 = tr[idx, 5] + off * np.cos(tr[idx, 3])
+    sim = VehicleSimulator(B, X0=X0, Y0=Y0, Psi0=tr[idx, 3], device=device)
+    loop = ClosedLoop(grt, sim, N=8, target_vel=8.0)
+    solve_s, its, worst = [], [], 0
+    for k in range(5):
+        loop.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):          # free-running: nothing waits for the host inside the loop
+        o = loop.step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    for k in range(10):             # the solve alone, bracketed by device synchronisations
+        o = loop.step(time_solve=True)
+        solve_s.append(o["solve_s"]); its.append(float(o["iters"].float().mean().item())); worst = max(worst, int(o["status"].max().item()))
+    return {"workload": "N=8, %d vehicles on path1 at 8 m/s, warm start, %d loop steps (waypoints + solve + 0.1 s of plant per step)" % (B, steps),
+            "vehicle_steps_per_s": B * steps / el, "ms_per_loop_step": el / steps * 1e3, "solve_ms_p50": float(np.percentile(solve_s, 50) * 1e3),
+            "mean_iterations": float(np.mean(its)), "worst_status": worst}
+
+
 def parity_sample(N, d, out, ro, tol=1e-6):
     """GPU vs the CPU port on the sampled problems.  The NLP is non-convex: on a few problems per thousand whose Hessian is
     indefinite along the way, rounding-level differences between the two implementations end in different local minima; those
@@ -380,6 +415,7 @@ def main():
             res["closed_loop_N8"] = closed_loop_latency(local)
             if Bl == 4096 and N == 20 and a.dtype == "f64" and not a.quick:
                 # the headline batch is one draw; the same workload over 8 other seeded batches (launch time = slowest problem of the draw)
+                res["closed_loop_fleet_N8_B4096"] = closed_loop_fleet(local)
                 res["multi_seed"] = multi_seed(solver, N, Bl, tdt, dev)
                 res["two_batches_in_flight"] = two_in_flight(N, Bl, tdt, din, local)
                 # the other single-GPU BASELINE configs, untimed-headline extra keys: configs[2] (fp32, B = 262144) and configs[4] (N = 50)

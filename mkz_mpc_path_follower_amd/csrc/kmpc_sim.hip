@@ -2,12 +2,39 @@
 // Restates scripts/vehicle_simulator.py:58-113 for B vehicles at once: one thread per vehicle (the model is a
 // 6-state ODE + 2 actuator lags -- there is nothing to share between lanes), fp64 like the reference, state kept in
 // registers across all sub-steps of a call, so a 0.1 s control period (10 model updates = 100 Euler sub-steps) costs one
-// read and one write of 64 B per vehicle.  FP contraction is off so that every product/sum rounds as in the reference; sin/cos/atan2 come from the device math library (<= 1-2 ulp from numpy's), so parity
-// with the numpy checker is to rounding, not bit-exact (tests/test_closed_loop.py states the tolerance).
+// read and one write of 64 B per vehicle.  FP contraction is off so that every product/sum rounds as in the reference; sin / cos / atan2 are the device
+// math library's or short polynomials on their small-argument ranges (both <= 1-2 ulp from numpy's), so parity with the numpy checker is to rounding,
+// not bit-exact (tests/test_closed_loop.py states the tolerance).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #pragma clang fp contract(off)
+
+// The 100 serial sub-steps of a control period are what this kernel's time is (one thread per vehicle): per sub-step two atan2, a sin / cos
+// pair of the heading, cos of the tyre angle and an fmod.  In the states a path follower visits their arguments are small, so the common case
+// takes a short polynomial (<= 1 ulp-level error, like libm's) and anything else the library call:
+//   atan2(y, x), x > 0, |y / x| <= 1/8 (slip angles): odd Taylor series to t^19 (next term 8^-21 / 21 < 1e-20 relative);
+//   cos(d), |d| <= 0.6 (tyre angle, actuator-lagged command within +-0.5): even series to d^18;
+//   the heading wrap only when psi + pi has left [0, 2 pi).
+__device__ __forceinline__ double sim_atan2_pos(double y, double x)   // x > 0
+{
+    const double t = y / x;
+    if (!(fabs(t) <= 0.125)) return atan2(y, x);
+    const double z = t * t;
+    double p = -1.0 / 19.0;
+    p = p * z + 1.0 / 17.0; p = p * z - 1.0 / 15.0; p = p * z + 1.0 / 13.0; p = p * z - 1.0 / 11.0; p = p * z + 1.0 / 9.0;
+    p = p * z - 1.0 / 7.0; p = p * z + 1.0 / 5.0; p = p * z - 1.0 / 3.0;
+    return t + t * (z * p);
+}
+__device__ __forceinline__ double sim_cos_small(double d)
+{
+    if (!(fabs(d) <= 0.6)) return cos(d);
+    const double z = d * d;
+    double p = -1.0 / 6402373705728000.0;
+    p = p * z + 1.0 / 20922789888000.0; p = p * z - 1.0 / 87178291200.0; p = p * z + 1.0 / 479001600.0; p = p * z - 1.0 / 3628800.0;
+    p = p * z + 1.0 / 40320.0; p = p * z - 1.0 / 720.0; p = p * z + 1.0 / 24.0; p = p * z - 0.5;
+    return 1.0 + z * p;
+}
 
 __global__ __launch_bounds__(256) void kmpc_sim_kernel(int B, double *__restrict__ state, const double *__restrict__ cmd, int n_updates)
 {
@@ -23,11 +50,14 @@ __global__ __launch_bounds__(256) void kmpc_sim_kernel(int B, double *__restrict
     for (int it = 0; it < n_updates * 10; ++it) {
         double alpha_f = 0.0, alpha_r = 0.0;
         if (fabs(vx) > 1e-6) {                                      // :75
-            alpha_f = df - atan2(vy + lf * wz, vx);                 // :76
-            alpha_r = -atan2(vy - lf * wz, vx);                     // :77 (lf where lr is expected -- as in the reference)
+            // vx >= 0 always (vx_n = max(0, .) below, 0 at the start), so |vx| > 1e-6 means vx > 0
+            alpha_f = df - sim_atan2_pos(vy + lf * wz, vx);         // :76
+            alpha_r = -sim_atan2_pos(vy - lf * wz, vx);             // :77 (lf where lr is expected -- as in the reference)
         }
         const double Fyf = C_alpha_f * alpha_f, Fyr = C_alpha_r * alpha_r;  // :80-81
-        const double cd = cos(df), sp = sin(psi), cp = cos(psi);
+        const double cd = sim_cos_small(df);
+        double sp, cp;
+        sincos(psi, &sp, &cp);
         // :84 reads `acc - 1/m*Fyf*np.sin(self.df) + self.wz*self.vy` with m = 1840 an int: the reference is Python 2 (print statements,
         // no `from __future__ import division`), so 1/m is INTEGER division = 0 and the lateral-force drag term vanishes (:88 uses 1.0/m)
         const double vx_n = fmax(0.0, vx + deltaT * (acc + wz * vy));
@@ -41,8 +71,11 @@ __global__ __launch_bounds__(256) void kmpc_sim_kernel(int B, double *__restrict
         const double Y_n = Y + deltaT * (vx * sp + vy * cp);        // :96
         X = X_n; Y = Y_n;
         const double a = psi_n + pi, p2 = 2.0 * pi;                 // :101  python's float % : result has the divisor's sign
-        double md = fmod(a, p2);
-        if (md < 0.0) md += p2;
+        double md = a;
+        if (!(a >= 0.0 && a < p2)) {                                // (a % p2 == a exactly while a is inside [0, p2))
+            md = fmod(a, p2);
+            if (md < 0.0) md += p2;
+        }
         psi = md - pi;
         vx = vx_n; vy = vy_n; wz = wz_n;
         acc = 5.0 * (acc_des - acc) * deltaT + acc;                 // :112
