@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KMPC_ABI_VERSION 5
+#define KMPC_ABI_VERSION 6
 
 /* per-problem status, replaces the Symbol returned by solve_model() (MKZMPCPathFollower.jl:176,182) */
 enum {
@@ -193,6 +193,17 @@ const char *kmpc_path_last_error(kmpc_path *p);
  *   cmd   [B,2] fp64 DEVICE: accel_cmd, steer_angle_cmd of MPC_cmd (:52-55)
  * Asynchronous on `stream` (NULL = the device's default stream).  Errors: negative code, text in kmpc_last_error(NULL). */
 int32_t kmpc_sim_advance_batch(int32_t device, int32_t B, void *state, const void *cmd, int32_t n_updates, void *stream);
+
+/* ---- command stage of the node's loop, for B vehicles (scripts/mpc_cmd_pub.jl) --------------------------------------
+ * What the loop does between solve_model() and the publish: the waypoint helper's stop flag latches (:100-103); a latched vehicle is
+ * commanded accel -1.0 / steer 0.0 (:148-153) and keeps its rate-limit anchor; every other vehicle publishes the solver's first input
+ * regardless of the solver status (:120-132) and update_current_input() remembers it for the next solve (:140).
+ *   u0 [B,2] fp64 DEVICE in: (accel, steer) from kmpc_solve_batch      stop [B] int32 DEVICE in: kmpc_waypoints_batch's flag
+ *   stop_latch [B] uint8 DEVICE in/out                                  u_prev [B,2] fp64 DEVICE in/out (acc, steer)
+ *   cmd [B,2] fp64 DEVICE out: accel_cmd, steer_angle_cmd of MPC_cmd
+ * Asynchronous on `stream`.  Errors as kmpc_sim_advance_batch. */
+int32_t kmpc_command_batch(int32_t device, int32_t B, const void *u0, const int32_t *stop, uint8_t *stop_latch, void *u_prev, void *cmd,
+                           void *stream);
 
 #ifdef __cplusplus
 }

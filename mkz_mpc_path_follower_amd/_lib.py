@@ -29,7 +29,7 @@ EXPORTS = ["kmpc_abi_version", "kmpc_config_default", "kmpc_create", "kmpc_destr
            "kmpc_get_cost", "kmpc_solve_batch", "kmpc_solve_batch_host", "kmpc_last_error",
            "kmpc_debug_condense", "kmpc_debug_mfma_probe",
            "kmpc_path_create", "kmpc_path_destroy", "kmpc_waypoints_batch", "kmpc_path_last_error",
-           "kmpc_sim_advance_batch", "kmpc_solve_batch_frenet", "kmpc_debug_kkt"]
+           "kmpc_sim_advance_batch", "kmpc_solve_batch_frenet", "kmpc_debug_kkt", "kmpc_command_batch"]
 
 _lib = None
 
@@ -66,6 +66,7 @@ def load():
     L.kmpc_path_last_error.argtypes = [vp]
     L.kmpc_path_last_error.restype = C.c_char_p
     L.kmpc_sim_advance_batch.argtypes = [i32, i32, vp, vp, i32, vp]
+    L.kmpc_command_batch.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

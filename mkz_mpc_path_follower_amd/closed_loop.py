@@ -8,8 +8,11 @@ rate-limit anchor is the last *command*, not the measured actuator state (:140, 
 helper latches and overrides the command with accel -1.0 / steer 0.0 (:100-103, :148-153), per vehicle; warm start
 from the previous primal solution (JuMP keeps values, Q9).
 """
+import ctypes as C
+
 import torch
 
+from . import _lib
 from .solver import BatchMPC
 
 
@@ -27,7 +30,8 @@ class ClosedLoop:
         self.v_target = torch.full((self.B,), self.des_speed, dtype=torch.float64, device=dev)
         self.u_prev = torch.zeros((self.B, 2), dtype=torch.float64, device=dev)       # (acc, d_f): update_current_input starts at 0
         self.warm_U = torch.zeros((self.B, self.N, 2), dtype=torch.float64, device=dev)
-        self.command_stop = torch.zeros((self.B,), dtype=torch.bool, device=dev)
+        self.command_stop = torch.zeros((self.B,), dtype=torch.bool, device=dev)   # the stop latch (one byte per vehicle: kmpc_command_batch's uint8)
+        self._lib = _lib.load()
         self.have_warm = False
         self.out = None
         self.k = 0
@@ -38,7 +42,6 @@ class ClosedLoop:
         st = self.sim.state
         pose = st[:, 0:3].contiguous()
         ref, stop = self.grt.get_waypoints_batch(pose, None if self.track_with_time else self.v_target)
-        self.command_stop |= stop.bool()                                            # :100-103
         z0 = st[:, 0:4].contiguous()                                                # x, y, psi, v = vx  (state_est, :43-46 of the simulator)
         if time_solve:
             torch.cuda.synchronize()
@@ -49,12 +52,13 @@ class ClosedLoop:
             torch.cuda.synchronize()
             solve_s = time.perf_counter() - t0
         self.have_warm = True
-        u0 = self.out["u0"]
-        stopc = self.command_stop.unsqueeze(1)
-        stop_cmd = torch.tensor([-1.0, 0.0], dtype=torch.float64, device=u0.device)
-        cmd = torch.where(stopc, stop_cmd, u0)                                       # :148-153
-        self.u_prev = torch.where(stopc, self.u_prev, u0)                            # :140 (only on the solve branch)
-        self.sim.cmd.copy_(cmd)
+        # stop latch (:100-103), command selection (:148-153) and update_current_input (:140, only on the solve branch): one kernel, straight
+        # into the plant's command buffer
+        cmd = self.sim.cmd
+        stream = C.c_void_p(torch.cuda.current_stream(cmd.device).cuda_stream)
+        _lib.check(self._lib.kmpc_command_batch(cmd.device.index, self.B, C.c_void_p(self.out["u0"].data_ptr()), C.c_void_p(stop.data_ptr()),
+                                                C.c_void_p(self.command_stop.data_ptr()), C.c_void_p(self.u_prev.data_ptr()),
+                                                C.c_void_p(cmd.data_ptr()), stream))
         self.sim._update_vehicle_model(plant_updates)
         self.k += 1
         return dict(ref=ref, cmd=cmd, status=self.out["status"], iters=self.out["iters"], cost=self.out["cost"], solve_s=solve_s)

@@ -24,6 +24,7 @@ template <typename T> hipError_t kmpc_launch_solve_fast_frenet(const KP &, const
 template <typename T> hipError_t kmpc_launch_fast_kkt(const KP &, const KDbgK<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_wide_kkt(const KP &, const KDbgK<T> &, hipStream_t);
 hipError_t kmpc_launch_sim(int, double *, const double *, int, hipStream_t);
+hipError_t kmpc_launch_command(int, const double *, const int32_t *, uint8_t *, double *, double *, hipStream_t);
 template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, const T *, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
 
 struct kmpc_handle {
@@ -452,5 +453,15 @@ extern "C" int32_t kmpc_sim_advance_batch(int32_t device, int32_t B, void *state
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, KMPC_ERR_HIP, "kmpc_sim_advance_batch: hipSetDevice(%d) failed", device);
     const hipError_t e = kmpc_launch_sim(B, (double *)state, (const double *)cmd, n_updates, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, KMPC_ERR_HIP, "kmpc_sim_advance_batch: %s", hipGetErrorString(e));
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_command_batch(int32_t device, int32_t B, const void *u0, const int32_t *stop, uint8_t *stop_latch, void *u_prev, void *cmd, void *stream)
+{
+    if (B < 0 || (B > 0 && (!u0 || !stop || !stop_latch || !u_prev || !cmd))) return fail(nullptr, KMPC_ERR_ARG, "kmpc_command_batch: bad argument (B=%d)", B);
+    if (B == 0) return KMPC_OK;
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, KMPC_ERR_HIP, "kmpc_command_batch: hipSetDevice(%d) failed", device);
+    const hipError_t e = kmpc_launch_command(B, (const double *)u0, stop, stop_latch, (double *)u_prev, (double *)cmd, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, KMPC_ERR_HIP, "kmpc_command_batch: %s", hipGetErrorString(e));
     return KMPC_OK;
 }

@@ -89,3 +89,25 @@ hipError_t kmpc_launch_sim(int B, double *state, const double *cmd, int n_update
     hipLaunchKernelGGL(kmpc_sim_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, state, cmd, n_updates);
     return hipGetLastError();
 }
+
+// The command stage of the node's loop for B vehicles (mpc_cmd_pub.jl): the waypoint helper's stop flag latches (:100-103); a latched vehicle
+// is commanded accel -1.0 / steer 0.0 (:148-153) and keeps its rate-limit anchor, any other publishes the solver's first input -- whatever the
+// solver status (:120-132, Q7) -- and remembers it as the anchor of the next solve (:140).
+__global__ __launch_bounds__(256) void kmpc_command_kernel(int B, const double *__restrict__ u0, const int32_t *__restrict__ stop, uint8_t *__restrict__ latch,
+                                                           double *__restrict__ u_prev, double *__restrict__ cmd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const bool st = latch[i] != 0 || stop[i] != 0;
+    latch[i] = st ? 1 : 0;
+    const double a = u0[2 * (size_t)i], d = u0[2 * (size_t)i + 1];
+    cmd[2 * (size_t)i] = st ? -1.0 : a;
+    cmd[2 * (size_t)i + 1] = st ? 0.0 : d;
+    if (!st) { u_prev[2 * (size_t)i] = a; u_prev[2 * (size_t)i + 1] = d; }
+}
+
+hipError_t kmpc_launch_command(int B, const double *u0, const int32_t *stop, uint8_t *latch, double *u_prev, double *cmd, hipStream_t st)
+{
+    hipLaunchKernelGGL(kmpc_command_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, u0, stop, latch, u_prev, cmd);
+    return hipGetLastError();
+}

@@ -8,6 +8,7 @@ sin/cos/atan2 differ from numpy's by <= 2 ulp per call, accumulated over 100-100
 import os
 
 import numpy as np
+import torch
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -148,3 +149,27 @@ def test_closed_loop_stop_latch():
     assert loop.command_stop.all().item()
     assert torch.equal(last["cmd"], torch.tensor([[-1.0, 0.0]] * B, dtype=torch.float64, device=last["cmd"].device))
     assert (sim.state[:, 3] == 0.0).all().item()
+
+
+@pytest.mark.gpu
+def test_command_stage_matches_the_node_loop():
+    """kmpc_command_batch = mpc_cmd_pub.jl:100-103 (stop latch), :148-153 (a latched vehicle gets accel -1 / steer 0), :140 (the published input is
+    the next solve's rate-limit anchor, only on the solve branch), for a batch: against the same rules written with torch.where"""
+    import ctypes as C
+    from mkz_mpc_path_follower_amd import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    B = 1000
+    u0 = torch.randn((B, 2), dtype=torch.float64, generator=g).cuda()
+    stop = (torch.rand((B,), generator=g) < 0.2).to(torch.int32).cuda()
+    latch = (torch.rand((B,), generator=g) < 0.3).cuda()
+    u_prev = torch.randn((B, 2), dtype=torch.float64, generator=g).cuda()
+    cmd = torch.full((B, 2), 7.0, dtype=torch.float64, device="cuda")
+    exp_latch = latch | stop.bool()
+    exp_cmd = torch.where(exp_latch.unsqueeze(1), torch.tensor([-1.0, 0.0], dtype=torch.float64, device="cuda"), u0)
+    exp_prev = torch.where(exp_latch.unsqueeze(1), u_prev, u0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert L.kmpc_command_batch(0, B, p(u0), p(stop), p(latch), p(u_prev), p(cmd), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(latch, exp_latch) and torch.equal(cmd, exp_cmd) and torch.equal(u_prev, exp_prev)
+    assert L.kmpc_command_batch(0, -1, p(u0), p(stop), p(latch), p(u_prev), p(cmd), None) < 0
