@@ -8,7 +8,10 @@ A "step" is one pass of the hot path (kmpc_solve_batch) over one batch of synthe
 segment) problems already resident in HBM, followed -- for N > 1 -- by the all-gather of the
 (accel, steer) blocks (RCCL; asynchronous and double-buffered, so the exchange of batch k overlaps the
 solve of batch k+1 -- every gather completes inside the timed region).  Workload at every N: BASELINE.json configs[1], batch = 4096 problems per
-GPU, horizon 20, fp64 (weak scaling: the batch is sharded, per-GPU work is fixed).
+GPU, horizon 20, fp64 (weak scaling: the batch is sharded, per-GPU work is fixed).  A launch of a few thousand problems takes as long as its
+slowest problem, so its time depends on the draw: every rank cycles through the SAME K_DRAWS seeded batches (rank r solves draw (step + r) % K),
+so `value` is a mean over draws and every rank does the same total work whatever N is.
+`--batch 262144 --gpus 8` is BASELINE.json configs[3] (2 097 152 problems over 8 GPUs) and labels itself so.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -50,10 +53,28 @@ def executed_flops_per_iteration(N):
     return 150 * N + 52 * N * (N + 1) + 40 * N + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
 
 
-def measured_traffic_bytes():
-    """(HBM bytes per 4096-problem dispatch, source) from the committed PMC passes (profiles/r*_pmc_traffic.json), or (None, None).
-    PMC counters need their own rocprofv3 passes (tools/pmc_quick.sh); this run does not collect them -- the figure is the
-    committed one of the same kernel build, and the JSON line says so."""
+def counter_profile(kernel):
+    """committed counter passes of one kernel (profiles/r*_pmc_*.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE and the SQ passes, each with the
+    command that produced it), newest round first, or None.  PMC counters need their own rocprofv3 passes (tools/pmc_quick.sh); a bench run does
+    not collect them -- the figures are the committed ones of the same kernel build and the JSON line says so."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                j = json.load(fh)
+            k = j.get("kernels", {}).get(kernel)
+            if k:
+                return dict(k, file="profiles/" + os.path.basename(f))
+        except Exception:
+            continue
+    return None
+
+
+def measured_traffic_bytes(kernel="kmpc_solve_fast_kernel<double,20>"):
+    """(HBM bytes per dispatch, source) of the headline kernel from the committed PMC passes, or (None, None)"""
+    k = counter_profile(kernel)
+    if k and k.get("hbm_bytes_per_dispatch"):
+        return float(k["hbm_bytes_per_dispatch"]), "%s (B = %s): committed rocprofv3 --pmc passes, not measured in this run" % (k["file"], k.get("batch"))
     for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -83,15 +104,16 @@ def multi_seed(solver, N, B, tdt, dev, seeds=8, steps=10, warmup=2):
     """The launch time of a few thousand problems is set by its slowest problems, so it depends on the draw: the same workload
     on `seeds` OTHER seeded batches (the headline batch is not among them)."""
     from mkz_mpc_path_follower_amd.synthetic import make_batch
-    rates, its = [], []
+    rates, its, opt = [], [], []
     for s in range(seeds):
         d = make_batch(B, N, cfg_id=2, seed=20180620 + 7919 * (s + 1))
         din = {k: torch.as_tensor(d[k], dtype=tdt, device=dev) for k in ("z0", "ref", "v_target", "u_prev")}
         ms, out = time_launches(solver, din, steps, warmup)
         rates.append(B / (ms * 1e-3)); its.append(out["iters"].float().mean().item())
-        assert int((out["status"] == 0).sum().item()) == B
+        opt.append(int((out["status"] == 0).sum().item()) / B)
     return {"seeds": seeds, "launches_per_seed": steps, "mean": float(np.mean(rates)), "min": float(np.min(rates)), "max": float(np.max(rates)),
-            "unit": "solves/s", "mean_iterations": float(np.mean(its)), "all_optimal": True}
+            "per_seed": [float(r) for r in rates], "unit": "solves/s", "mean_iterations": float(np.mean(its)),
+            "optimal_fraction": float(np.mean(opt)), "optimal_fraction_min": float(np.min(opt)), "all_optimal": bool(min(opt) == 1.0)}
 
 
 def two_in_flight(N, B, tdt, din, local, steps=40, warmup=6):
@@ -129,13 +151,22 @@ def other_config(N, B, dtype, cfg_id, dev, local, steps=5, warmup=2):
     ms, out = time_launches(solver, din, steps, warmup)
     iters = out["iters"].float().mean().item()
     peak = FP64_PEAK_TFLOPS if dtype == "f64" else FP32_PEAK_TFLOPS
-    tf = algorithmic_flops_per_iteration(N) * iters * B / (ms * 1e-3) / 1e12
+    tf = executed_flops_per_iteration(N) * iters * B / (ms * 1e-3) / 1e12
+    tf_model = algorithmic_flops_per_iteration(N) * iters * B / (ms * 1e-3) / 1e12
     es = 8 if dtype == "f64" else 4
-    return {"workload": "batch=%d, N=%d, %s, 1 GPU, seeded synthetic (cfg_id %d)" % (B, N, dtype, cfg_id), "solves_per_s": B / (ms * 1e-3),
-            "kernel_ms": ms, "launches": steps, "mean_iterations": iters, "max_iterations": int(out["iters"].max().item()),
-            "optimal_fraction": float((out["status"] == 0).float().mean().item()),
-            "achieved_tflops": tf, "peak_tflops": peak, "frac_of_peak": tf / peak,
-            "hbm_gbs_algorithmic": algorithmic_bytes_per_solve(N, es) * B / (ms * 1e-3) / 1e9}
+    r = {"workload": "batch=%d, N=%d, %s, 1 GPU, seeded synthetic (cfg_id %d)" % (B, N, dtype, cfg_id), "solves_per_s": B / (ms * 1e-3),
+         "kernel": kernel_name(N, dtype), "kernel_ms": ms, "launches": steps, "mean_iterations": iters, "max_iterations": int(out["iters"].max().item()),
+         "optimal_fraction": float((out["status"] == 0).float().mean().item()),
+         "achieved_tflops": tf, "peak_tflops": peak, "frac_of_peak": tf / peak, "frac_survey_model": tf_model / peak,
+         "flops_note": "frac_of_peak prices the flops the kernel executes (O(N^2) adjoint condensing); frac_survey_model the SURVEY 8(d) formula",
+         "hbm_gbs_algorithmic": algorithmic_bytes_per_solve(N, es) * B / (ms * 1e-3) / 1e9}
+    k = counter_profile(r["kernel"])
+    if k and k.get("hbm_bytes_per_dispatch") and k.get("batch") == B:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same kernel at the same batch (committed; corrected as MI355X_MICROARCH.md prescribes)
+        r["hbm_gbs_counters"] = float(k["hbm_bytes_per_dispatch"]) / (ms * 1e-3) / 1e9
+        r["hbm_frac_of_peak_counters"] = r["hbm_gbs_counters"] / HBM_PEAK_GBS
+        r["hbm_counters_source"] = "%s: committed rocprofv3 --pmc passes (bytes per dispatch), divided by this run's kernel time" % k["file"]
+    return r
 
 
 def closed_loop_latency(device, steps=150):
@@ -227,13 +258,16 @@ def parity_sample(N, d, out, ro, tol=1e-6):
     return info
 
 
-def kernel_name(N, dtype):
+def kernel_name(N, dtype, B=4096):
+    """the kernel kmpc_solve_batch dispatches (csrc/kmpc_api.hip: solve_dev; kmpc_fast_available / kmpc_wide_available / launch_fast_n)"""
     t = "double" if dtype == "f64" else "float"
-    if N in (8, 12, 16, 20, 24, 28):
+    if N in (8, 12, 16, 20, 24, 28):       # kmpc_fast_available: compile-time horizons with 2N + 1 <= 64
+        if N <= 12 and B > 2048:
+            return "kmpc_solve_fast_dense_kernel<%s,%d>" % (t, N)
         return "kmpc_solve_fast_kernel<%s,%d>" % (t, N)
-    if N == 50 and dtype == "f64":
-        return "kmpc_solve_wide_kernel<double,50>"
-    return "kmpc_solve_kernel<%s>" % t
+    if N in (32, 36, 40, 44, 48, 50):      # kmpc_wide_available: four waves per problem, both element types
+        return "kmpc_solve_wide_kernel<%s,%d>" % (t, N)
+    return "kmpc_solve_kernel<%s>" % t      # generic kernel (runtime horizon)
 
 
 def host_cores():
@@ -275,6 +309,71 @@ def cpu_baseline(N, d, budget_s=15.0):
     return dict(value=S * reps / el, unit="solves/s", cores=cores, kind="port",
                 sample="first %d of the %d-problem GPU batch x %d repeats, oracle/kmpc_condensed.c (scalar fp64 C, %d pthreads), "
                        "mean %.1f iterations" % (S, d["z0"].shape[0], reps, cores, float(r["iters"].mean()))), r
+
+
+def cpu_baseline_config1(n_cold=1000, n_warm=1000):
+    """BASELINE.md section 3 run C1: the CPU port (oracle/kmpc_condensed.c), ONE thread, BASELINE configs[0] -- the reference's module-load
+    problem (N = 8, z0 = 0, straight reference at 15 m/s, u_prev = 0, node weights; MKZMPCPathFollower.jl:36-39,110-113,127) solved cold
+    n_cold times, and its 10 Hz receding-horizon continuation (state advanced by the model's own Euler step over dt_control with the first
+    input, reference re-anchored at the car as the time-mode waypoint helper does, warm start from the previous primal solution as JuMP
+    keeps it, Q9).  Per-solve wall time around the C call; the reference's only figure is its 0.1 s cap (MKZMPCPathFollower.jl:29)."""
+    from oracle import oracle as O
+    N = 8
+    p = O.params(N)
+    ref = np.zeros((N + 1, 3)); ref[:, 0] = 15.0 * 0.2 * np.arange(N + 1)
+    q = O.problem(p, np.zeros(4), ref, 15.0, (0.0, 0.0))
+    o = O.opts()
+    cold, r = [], None
+    for _ in range(n_cold + 20):
+        t = time.perf_counter()
+        r = O.solve_condensed(p, q, o)
+        cold.append(time.perf_counter() - t)
+    cold = np.array(cold[20:]) * 1e6
+    cold_cost, cold_iters, cold_status = r["cost"], r["iters"], r["status"]
+    ow = O.opts(warm=1)
+    z = np.zeros(4); up = np.zeros(2); U = r["U"].copy()
+    rr = p.L_b / (p.L_a + p.L_b)
+    warm, its, worst = [], [], 0
+    for k in range(n_warm):
+        a, d = U[0]
+        beta = np.arctan(rr * np.tan(d))                                   # MKZMPCPathFollower.jl:115-122 over dt_control
+        z = z + p.dt_control * np.array([z[3] * np.cos(z[2] + beta), z[3] * np.sin(z[2] + beta), z[3] / p.L_b * np.sin(beta), a])
+        up = np.array([a, d])
+        refk = np.zeros((N + 1, 3)); refk[:, 0] = z[0] + 15.0 * 0.2 * np.arange(N + 1)
+        qk = O.problem(p, z, refk, 15.0, up)
+        t = time.perf_counter()
+        r = O.solve_condensed(p, qk, ow, U0=U)
+        warm.append(time.perf_counter() - t)
+        U = r["U"]; its.append(r["iters"]); worst = max(worst, r["status"])
+    warm = np.array(warm) * 1e6
+    return {"workload": "BASELINE configs[0]: single N=8 problem (module-load problem of MKZMPCPathFollower.jl), CPU port, 1 thread",
+            "kind": "port", "cores": 1, "cold": {"solves": n_cold, "p50_us": float(np.percentile(cold, 50)), "p99_us": float(np.percentile(cold, 99)),
+                                                   "cost": cold_cost, "iterations": cold_iters, "status": cold_status},
+            "warm_10hz": {"solves": n_warm, "p50_us": float(np.percentile(warm, 50)), "p99_us": float(np.percentile(warm, 99)),
+                          "mean_iterations": float(np.mean(its)), "worst_status": worst, "final_speed": float(z[3])},
+            "reference_cap_us": 1e5, "note": "the reference caps one Ipopt solve at 0.1 s CPU (max_cpu_time = dt_control); its own timing is unavailable (no julia)"}
+
+
+def gpu_config1_latency(local, n=300):
+    """the same module-load problem on the GPU, B = 1, cold, device-resident inputs: host clock around launch + sync"""
+    from mkz_mpc_path_follower_amd import BatchMPC
+    from mkz_mpc_path_follower_amd.synthetic import straight_line_case
+    d = straight_line_case(8)
+    sv = BatchMPC(N=8, device=local)
+    din = {k: torch.as_tensor(d[k], dtype=torch.float64, device=sv.device) for k in ("z0", "ref", "v_target", "u_prev")}
+    o, lat = None, []
+    for i in range(n + 20):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        o = sv.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=o)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t)
+    w = np.array(lat[20:]) * 1e6
+    return {"workload": "BASELINE configs[0] on the GPU: module-load problem, N=8, B=1, cold, resident inputs", "p50_us": float(np.percentile(w, 50)),
+            "p99_us": float(np.percentile(w, 99)), "cost": float(o["cost"][0].item()), "iterations": int(o["iters"][0].item()), "status": int(o["status"][0].item())}
+
+
+K_DRAWS = 4   # seeded batches every rank cycles through (draw 0 is the batch rounds 1-2 quoted alone)
 
 
 def main():
@@ -325,36 +424,50 @@ def main():
     tdt = torch.float64 if a.dtype == "f64" else torch.float32
     es = 8 if a.dtype == "f64" else 4
     B = Bl * world
-    # every rank draws its own shard of the seeded global batch (no scatter)
-    d = make_batch(Bl, N, cfg_id=2, seed=20180620 + 2 + 1000 * rank)
-    din = {k: torch.as_tensor(d[k], dtype=tdt, device=dev) for k in ("z0", "ref", "v_target", "u_prev")}
+    # every rank generates the same K seeded draws locally (no scatter) and solves draw (step + rank) % K at each step: equal total work on
+    # every rank and at every N, different problems in flight on different GPUs at any one time
+    K = K_DRAWS
+    draws = [make_batch(Bl, N, cfg_id=2, seed=20180620 + 2 + 7919 * j) for j in range(K)]
+    d = draws[0]
+    dins = [{k: torch.as_tensor(dj[k], dtype=tdt, device=dev) for k in ("z0", "ref", "v_target", "u_prev")} for dj in draws]
+    din = dins[0]
     solver = BatchMPC(N=N, dtype=tdt, device=local)
-    # N > 1: the all-gather of batch k's (accel, steer) block runs asynchronously on the collective's stream while batch k+1 is
-    # solved; two output slots alternate, and a slot's gather is waited for before a solve may overwrite the buffer it reads.
+    # N > 1: the all-gather of batch k's (accel, steer) block runs asynchronously on the collective's stream while later batches are
+    # solved; K output slots alternate (a rank may run up to K steps ahead of the slowest one -- over K steps every rank has done the same
+    # work), and a slot's gather is waited for before a solve may overwrite the buffer it reads.
     # Every step's gather completes inside the timed region (final waits + synchronize below).
-    gather = SolutionGather(B)
-    outs = [None, None]
+    gather = SolutionGather(B, slots=K)
+    outs = [None] * K
 
     for i in range(a.warmup):
-        s = i & 1
+        s = i % K
         gather.wait(s)
-        outs[s] = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=outs[s])
+        dj = dins[(i + rank) % K]
+        outs[s] = solver.solve(dj["z0"], dj["ref"], dj["v_target"], dj["u_prev"], out=outs[s])
         gather.submit(s, outs[s]["u0"])
-    gather.wait(0); gather.wait(1)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    for s in range(K):
+        gather.wait(s)
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(a.steps)]
+    it_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    n_opt_t = torch.zeros((), dtype=torch.int64, device=dev)
+    wait_host = 0.0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        s = i & 1
+        s = i % K
+        ev[i][0].record()
+        tw = time.perf_counter()
         gather.wait(s)
-        ev[i][0].record()   # same stream the kernel is launched on (torch's current stream is handed to the C ABI)
-        outs[s] = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], out=outs[s])
-        ev[i][1].record()
+        wait_host += time.perf_counter() - tw
+        dj = dins[(a.warmup + i + rank) % K]
+        ev[i][1].record()   # same stream the kernel is launched on (torch's current stream is handed to the C ABI)
+        outs[s] = solver.solve(dj["z0"], dj["ref"], dj["v_target"], dj["u_prev"], out=outs[s])
+        ev[i][2].record()
         gather.submit(s, outs[s]["u0"])
-    gather.wait(0); gather.wait(1)
-    out = outs[(a.steps - 1) & 1]
+    for s in range(K):
+        gather.wait(s)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -363,42 +476,76 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
-    iters = out["iters"].float().mean().item()
-    status = out["status"]
-    n_opt = int((status == 0).sum().item())
+    kern = np.array([e[1].elapsed_time(e[2]) for e in ev])
+    kern_ms = float(kern.mean())
+    wait_stream_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    # iteration counts / statuses of the K draws (the last launch of each is still in its slot when steps >= K)
+    live = [o for o in outs if o is not None]
+    iters = float(np.mean([o["iters"].float().mean().item() for o in live]))
+    n_opt = int(sum(int((o["status"] == 0).sum().item()) for o in live))
+    n_tot = Bl * len(live)
+    out = outs[(a.steps - 1) % K]
+    per_draw = [None] * K
+    for i in range(a.steps):
+        j = (a.warmup + i + rank) % K
+        per_draw[j] = (per_draw[j] or []) + [kern[i]]
+    per_draw_ms = [float(np.mean(x)) if x else None for x in per_draw]
+    # per-rank diagnostics for the N > 1 line: what each rank's kernel took, how long its solve stream stood waiting for a gather, its iterations
+    mine = torch.tensor([kern_ms, float(kern.min()), float(kern.max()), wait_stream_ms, wait_host / a.steps * 1e3, iters], dtype=torch.float64,
+                        device=dev if a.backend == "nccl" else "cpu")
+    if world > 1:
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+    else:
+        allr = mine.cpu().numpy()[None]
 
     res = None
     if rank == 0:
         value = B * a.steps / el
-        flops = algorithmic_flops_per_iteration(N) * iters * Bl
+        peak = FP64_PEAK_TFLOPS if a.dtype == "f64" else FP32_PEAK_TFLOPS
+        kname = kernel_name(N, a.dtype, Bl)
+        flops_exec = executed_flops_per_iteration(N) * iters * Bl       # what one launch executes
+        flops_model = algorithmic_flops_per_iteration(N) * iters * Bl   # SURVEY.md 8(d) formula (O(N^3) structured condensing)
         byts = algorithmic_bytes_per_solve(N, es) * Bl
-        ach_tf = flops / (kern_ms * 1e-3) / 1e12
+        ach_tf = flops_exec / (kern_ms * 1e-3) / 1e12
         ach_gbs = byts / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic_bytes() if (world == 1 and Bl == 4096 and N == 20 and a.dtype == "f64") else (None, None)
+        traffic, traffic_src = measured_traffic_bytes(kname) if (world == 1 and Bl == 4096 and N == 20 and a.dtype == "f64") else (None, None)
+        cfg_label = ("BASELINE configs[3]: batch=%d sharded across %d GPUs (%d problems per GPU), N=%d, %s, all-gather of (accel, steer)" % (B, world, Bl, N, a.dtype)
+                     if (world == 8 and Bl == 262144 and N == 20) else
+                     "BASELINE configs[1]: batch=%d problems per GPU, N=%d, %s, one wavefront per problem" % (Bl, N, a.dtype))
         res = {
             "metric": "MPC solves/sec (batch, N=20 bicycle)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch=%d problems per GPU, N=%d, %s, one wavefront per problem"
-                                   % (Bl, N, a.dtype),
-                       "batch_per_gpu": Bl, "global_batch": B, "horizon": N, "parallelism": "shard%d" % world,
-                       "mean_iterations": iters, "optimal_fraction": n_opt / Bl},
+            "config": {"workload": cfg_label + "; every rank cycles through the same %d seeded draws (rank r solves draw (step + r) %% %d)" % (K, K),
+                       "batch_per_gpu": Bl, "global_batch": B, "horizon": N, "parallelism": "shard%d" % world, "draws": K,
+                       "draw_seeds": [20180620 + 2 + 7919 * j for j in range(K)], "kernel_ms_per_draw": per_draw_ms,
+                       "mean_iterations": iters, "optimal_fraction": n_opt / n_tot},
             # the path is compute/latency-bound.  The SQ counters (profiles/r*_sq_counters.json) say the kernel is bound by
             # fp64 VALU ISSUE while the chip is full and by single-wave latency in the tail, not by the matrix cores; the denominator is the
-            # fp64 vector = fp64 MFMA peak (78.6 TFLOP/s), the numerator counts ALGORITHMIC flops only (SURVEY.md 8(d) formula)
-            "roofline": {"bound": "valu", "bound_note": "fp64 VALU issue / wave latency (MFMA pipes ~11 % busy); priced against the fp64 vector = MFMA peak",
-                         "achieved": ach_tf, "peak": (FP64_PEAK_TFLOPS if a.dtype == "f64" else FP32_PEAK_TFLOPS), "unit": "TFLOP/s",
-                         "frac": ach_tf / (FP64_PEAK_TFLOPS if a.dtype == "f64" else FP32_PEAK_TFLOPS), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_name(N, a.dtype), "kernel_ms": kern_ms,
-                         "flops_per_solve": algorithmic_flops_per_iteration(N) * iters,
-                         "executed_flops_per_solve": executed_flops_per_iteration(N) * iters,
-                         "frac_executed": executed_flops_per_iteration(N) * iters * Bl / (kern_ms * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS if a.dtype == "f64" else FP32_PEAK_TFLOPS),
-                         "flops_note": "frac prices the SURVEY 8(d) flop model (O(N^3) structured condensing, 16 k^2 per stage); the kernels condense in O(N^2) "
-                                       "(adjoint recursion), frac_executed prices the arithmetic they actually issue"},
+            # fp64 vector = fp64 MFMA peak (78.6 TFLOP/s), the numerator the flops the kernel EXECUTES per launch (the SURVEY 8(d) model,
+            # whose O(N^3) condensing term the kernels no longer run, is kept beside it as frac_survey_model so that rounds compare)
+            "roofline": {"bound": "valu", "bound_note": "fp64 VALU issue while the chip is full, single-wave latency in the tail; MFMA pipes ~4-5 % busy "
+                                                        "(profiles/r2_v4_sq_counters.json); priced against the fp64 vector = MFMA peak",
+                         "achieved": ach_tf, "peak": peak, "unit": "TFLOP/s", "frac": ach_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname, "kernel_ms": kern_ms, "launches_timed": a.steps,
+                         "flops_per_solve": executed_flops_per_iteration(N) * iters,
+                         "achieved_survey_model": flops_model / (kern_ms * 1e-3) / 1e12, "frac_survey_model": flops_model / (kern_ms * 1e-3) / 1e12 / peak,
+                         "survey_model_flops_per_solve": algorithmic_flops_per_iteration(N) * iters,
+                         "flops_note": "achieved / frac price the arithmetic the kernel issues (condensing by the O(N^2) adjoint recursion: 52 N (N+1) "
+                                       "flops per iteration); frac_survey_model prices SURVEY 8(d)'s formula (sum 16 k^2 + 32 N^2 for that stage)"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": byts,
                              "bytes_per_solve": algorithmic_bytes_per_solve(N, es)},
+            # one row per rank: with N > 1 a step runs at the pace of the ranks it is coupled to through the gathers; these say whether a
+            # slow line is a slow kernel (draw), a rank waiting for others' gathers, or the collective itself
+            "ranks": {"kernel_ms_mean": [float(x) for x in allr[:, 0]], "kernel_ms_min": [float(x) for x in allr[:, 1]],
+                      "kernel_ms_max": [float(x) for x in allr[:, 2]], "gather_wait_stream_ms": [float(x) for x in allr[:, 3]],
+                      "gather_wait_host_ms": [float(x) for x in allr[:, 4]], "mean_iterations": [float(x) for x in allr[:, 5]],
+                      "summary": {"kernel_ms": {"min": float(allr[:, 0].min()), "mean": float(allr[:, 0].mean()), "max": float(allr[:, 0].max())},
+                                  "gather_wait_stream_ms": {"min": float(allr[:, 3].min()), "mean": float(allr[:, 3].mean()), "max": float(allr[:, 3].max())}},
+                      "note": "gather_wait_*: time per step the solve stream (device events) / the host stood in SolutionGather.wait before a launch"},
         }
         if world == 1:
             # p50 per-solve latency: B = 1 through the same entry point, host clock around launch + sync
@@ -413,8 +560,9 @@ def main():
                 lat.append(time.perf_counter() - t)
             res["p50_latency_us_B1"] = float(np.percentile(lat[10:], 50) * 1e6)
             res["closed_loop_N8"] = closed_loop_latency(local)
+            res["config1_gpu_B1_cold"] = gpu_config1_latency(local)
             if Bl == 4096 and N == 20 and a.dtype == "f64" and not a.quick:
-                # the headline batch is one draw; the same workload over 8 other seeded batches (launch time = slowest problem of the draw)
+                # the headline cycles through K draws; the same workload over 8 OTHER seeded batches (launch time = slowest problem of the draw)
                 res["closed_loop_fleet_N8_B4096"] = closed_loop_fleet(local)
                 res["multi_seed"] = multi_seed(solver, N, Bl, tdt, dev)
                 res["two_batches_in_flight"] = two_in_flight(N, Bl, tdt, din, local)
@@ -429,6 +577,7 @@ def main():
             if not a.no_cpu_baseline:
                 cb, ro = cpu_baseline(N, d)
                 res["cpu_baseline"] = cb
+                res["cpu_baseline_config1"] = cpu_baseline_config1()   # BASELINE.md section 3, run C1 (beside closed_loop_N8 / config1_gpu_B1_cold)
                 out = solver.solve(din["z0"], din["ref"], din["v_target"], din["u_prev"], want_U=True)  # untimed, with the input trajectories
                 torch.cuda.synchronize()
                 # parity spot check of the timed batch against the CPU port on the sampled problems

@@ -24,6 +24,10 @@ class ClosedLoop:
         self.grt, self.sim, self.N = grt, sim, int(N)
         self.B = sim.B
         self.mpc = mpc if mpc is not None else BatchMPC(N=N, dtype=torch.float64, device=sim.device.index, weights=weights, **options)
+        # kmpc_command_batch reads the solver's first inputs as [B,2] doubles on the plant's device: a caller-supplied solver must match
+        if self.mpc.dtype != torch.float64 or self.mpc.N != self.N or self.mpc.device != sim.device or sim.device.index is None:
+            raise ValueError("ClosedLoop needs a float64 BatchMPC with horizon %d on %s (got %s, N=%d, %s)"
+                             % (self.N, sim.device, self.mpc.dtype, self.mpc.N, self.mpc.device))
         self.track_with_time = track_with_time
         self.des_speed = float(target_vel) if target_vel > 0.0 else 0.0  # mpc_cmd_pub.jl:58-62
         dev = sim.device
@@ -55,8 +59,10 @@ class ClosedLoop:
         # stop latch (:100-103), command selection (:148-153) and update_current_input (:140, only on the solve branch): one kernel, straight
         # into the plant's command buffer
         cmd = self.sim.cmd
+        u0 = self.out["u0"]
+        assert u0.dtype == torch.float64 and u0.is_contiguous() and u0.device == cmd.device and u0.shape == (self.B, 2)
         stream = C.c_void_p(torch.cuda.current_stream(cmd.device).cuda_stream)
-        _lib.check(self._lib.kmpc_command_batch(cmd.device.index, self.B, C.c_void_p(self.out["u0"].data_ptr()), C.c_void_p(stop.data_ptr()),
+        _lib.check(self._lib.kmpc_command_batch(cmd.device.index, self.B, C.c_void_p(u0.data_ptr()), C.c_void_p(stop.data_ptr()),
                                                 C.c_void_p(self.command_stop.data_ptr()), C.c_void_p(self.u_prev.data_ptr()),
                                                 C.c_void_p(cmd.data_ptr()), stream))
         self.sim._update_vehicle_model(plant_updates)

@@ -16,10 +16,10 @@
 //   atan2(y, x), x > 0, |y / x| <= 1/8 (slip angles): odd Taylor series to t^19 (next term 8^-21 / 21 < 1e-20 relative);
 //   cos(d), |d| <= 0.6 (tyre angle, actuator-lagged command within +-0.5): even series to d^18;
 //   the heading wrap only when psi + pi has left [0, 2 pi).
-__device__ __forceinline__ double sim_atan2_pos(double y, double x)   // x > 0
+__device__ __forceinline__ double sim_atan2_pos(double y, double x)   // polynomial branch only for x > 0 (a caller-written state may carry vx < 0)
 {
     const double t = y / x;
-    if (!(fabs(t) <= 0.125)) return atan2(y, x);
+    if (!(x > 0.0 && fabs(t) <= 0.125)) return atan2(y, x);
     const double z = t * t;
     double p = -1.0 / 19.0;
     p = p * z + 1.0 / 17.0; p = p * z - 1.0 / 15.0; p = p * z + 1.0 / 13.0; p = p * z - 1.0 / 11.0; p = p * z + 1.0 / 9.0;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void kmpc_sim_kernel(int B, double *__restrict
     for (int it = 0; it < n_updates * 10; ++it) {
         double alpha_f = 0.0, alpha_r = 0.0;
         if (fabs(vx) > 1e-6) {                                      // :75
-            // vx >= 0 always (vx_n = max(0, .) below, 0 at the start), so |vx| > 1e-6 means vx > 0
+            // states this kernel produced have vx >= 0 (vx_n = max(0, .) below); a negative vx written by the caller takes atan2's own quadrant logic
             alpha_f = df - sim_atan2_pos(vy + lf * wz, vx);         // :76
             alpha_r = -sim_atan2_pos(vy - lf * wz, vx);             // :77 (lf where lr is expected -- as in the reference)
         }

@@ -39,8 +39,8 @@ class SolutionGather:
 
     `submit(slot, u0_local)` starts the gather of one batch on the collective's own stream (RCCL: the copy engines / xGMI run it
     while the next batch's solve kernel computes); `wait(slot)` makes the current stream wait for it and returns the [B, 2]
-    result.  The caller alternates two slots and must `wait(slot)` before it lets a solve overwrite the `u0_local` buffer that
-    slot's gather reads -- `bench.py` does exactly that, so a step's solution exchange costs no time on the solve stream.
+    result.  The caller alternates its slots (two, or as many as the steps a rank may run ahead of the others) and must `wait(slot)`
+    before it lets a solve overwrite the `u0_local` buffer that slot's gather reads -- `bench.py` does exactly that, so a step's solution exchange costs no time on the solve stream.
     Equal shards only (the ragged case uses `all_gather_solutions`)."""
 
     def __init__(self, B, group=None, slots=2, force_collective=False):

@@ -49,13 +49,11 @@ def start_mpc_node(N=8, rospy=None, msgs=None, std_msgs=None, grt=None, mpc=None
         if topic == "enable":
             pubs[topic].publish(std_msgs.Empty())
         elif topic == "mpc_cmd":
-            out = msgs.MPC_cmd()
-            out.header.stamp = rospy.get_rostime()  # :126
+            out = msgs.MPC_cmd()   # the reference reads get_rostime() (:124) but never stamps the header: left default, as there
             out.accel_cmd, out.steer_angle_cmd = m.accel_cmd, m.steer_angle_cmd
             pubs[topic].publish(out)
         else:
             out = msgs.mpc_path()
-            out.header.stamp = rospy.get_rostime()
             out.xs, out.ys, out.psis = list(m.xs), list(m.ys), list(m.psis)
             pubs[topic].publish(out)
 

@@ -75,10 +75,10 @@ class BatchMPC:
         return t
 
     def _outputs(self, out, B, want_U, want_X):
-        """output tensors of one call: those in `out` are reused when they fit (B, dtype, device), anything else is (re)allocated --
-        a buffer left over from a call with another batch size or element type must never reach the kernel as a raw pointer"""
+        """output tensors of one call: those in `out` are reused when they fit (B, N, dtype, device), anything else is (re)allocated --
+        a buffer left over from a call with another batch size, horizon or element type must never reach the kernel as a raw pointer"""
         N = self.N
-        key = (B, want_U, want_X, self.dtype, self.device)
+        key = (B, N, want_U, want_X, self.dtype, self.device)  # U [B,N,2] and X [B,N+1,4] depend on the horizon
         if type(out) is _Out and out.fits == key and all(out.get(k) is t for k, t in out.refs):
             return out  # the dict of the previous call with the very same tensor objects: checked then
         o = _Out(out) if out is not None else _Out()

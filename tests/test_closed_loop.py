@@ -88,6 +88,22 @@ def test_sim_kernel_matches_oracle():
     assert np.isfinite(got).all() and np.abs(got[~mv, 4:6]).max() < 2.0
     assert (~mv).sum() > 100 and (exp[~mv, 3] > 0).sum() > 50   # the stratum is there and some of it does pull away
     assert (got[:, 3] >= 0).all()
+    # a caller-written state may carry vx < 0 (the kernel itself never produces one): the slip angles of that first sub-step go through
+    # atan2's own quadrant logic as np.arctan2 does in the reference (:76-77), vx is clamped to 0 (:84) and a braking car then stays at rest
+    B2 = 256
+    s1 = np.zeros((B2, 8))
+    s1[:, 0:2] = rng.uniform(-50, 50, (B2, 2)); s1[:, 2] = rng.uniform(-np.pi, np.pi, B2)
+    s1[:, 3] = -rng.uniform(0.01, 5.0, B2); s1[:, 4] = rng.normal(0, 0.2, B2); s1[:, 5] = rng.normal(0, 0.1, B2)
+    s1[:, 6] = -rng.uniform(0.2, 1.0, B2); s1[:, 7] = rng.uniform(-0.5, 0.5, B2)
+    cmd1 = np.stack([-rng.uniform(0.2, 1.0, B2), rng.uniform(-0.5, 0.5, B2)], 1)
+    sim1 = VehicleSimulator(B2)
+    sim1.state.copy_(torch.as_tensor(s1))
+    sim1._mpc_cmd_callback(cmd1[:, 0], cmd1[:, 1])
+    sim1._update_vehicle_model(10)
+    got1 = sim1.state.cpu().numpy()
+    exp1 = V.update_vehicle_model(s1, cmd1, n_updates=10)
+    assert np.abs(got1[:, 0:2] - exp1[:, 0:2]).max() < 1e-9 and np.abs(got1[:, 3:] - exp1[:, 3:]).max() < 1e-10
+    assert np.abs((got1[:, 2] - exp1[:, 2] + np.pi) % (2 * np.pi) - np.pi).max() < 1e-10 and (got1[:, 3] == 0).all()
 
 
 @pytest.mark.gpu
@@ -173,3 +189,101 @@ def test_command_stage_matches_the_node_loop():
     torch.cuda.synchronize()
     assert torch.equal(latch, exp_latch) and torch.equal(cmd, exp_cmd) and torch.equal(u_prev, exp_prev)
     assert L.kmpc_command_batch(0, -1, p(u0), p(stop), p(latch), p(u_prev), p(cmd), None) < 0
+
+
+@pytest.mark.gpu
+def test_closed_loop_rejects_a_solver_of_the_wrong_type():
+    """kmpc_command_batch reads the solver's first inputs as [B,2] doubles -- a caller-supplied fp32 / other-horizon BatchMPC is refused"""
+    import torch
+    from mkz_mpc_path_follower_amd import BatchMPC
+    from mkz_mpc_path_follower_amd.ref_traj import GPSRefTrajectory
+    from mkz_mpc_path_follower_amd.vehicle_sim import VehicleSimulator
+    from mkz_mpc_path_follower_amd.closed_loop import ClosedLoop
+    grt = GPSRefTrajectory(arrays=_path_arrays(), traj_horizon=8, traj_dt=0.2)
+    sim = VehicleSimulator(4)
+    with pytest.raises(ValueError, match="float64"):
+        ClosedLoop(grt, sim, N=8, mpc=BatchMPC(N=8, dtype=torch.float32))
+    with pytest.raises(ValueError, match="float64"):
+        ClosedLoop(grt, sim, N=8, mpc=BatchMPC(N=12))
+    ClosedLoop(grt, sim, N=8, mpc=BatchMPC(N=8))
+
+
+@pytest.mark.gpu
+def test_ros_adapter_drives_the_real_solver():
+    """ros_node.start_mpc_node (mpc_cmd_pub.jl:158-175) with a stub rospy but the REAL KinematicMPC and GPSRefTrajectory on
+    the recorded path, closed through the plant the way launch/sim_path_follow.launch wires it: the stub's Rate.sleep() advances the
+    simulator by one control period with the last published MPC_cmd and delivers the next state_est.  Checks the topic order of
+    :129-147, finite bounded commands, the steer-first feedback (Q6) through the first-step rate limit, and the stop latch (:148-153)."""
+    import types
+    import torch
+    from mkz_mpc_path_follower_amd import ros_node
+    from mkz_mpc_path_follower_amd.kinematic_mpc import KinematicMPC
+    from mkz_mpc_path_follower_amd.ref_traj import GPSRefTrajectory
+    from mkz_mpc_path_follower_amd.vehicle_sim import VehicleSimulator
+    N, vt = 8, 6.0
+    grt = GPSRefTrajectory(arrays=_path_arrays(), traj_horizon=N, traj_dt=0.2)
+    tr = grt.get_global_trajectory_reference()
+    i0 = len(tr) - 90                                   # ~20 m before the end of the path: the stop flag comes up within the run
+    sim = VehicleSimulator(1, X0=tr[i0, 4], Y0=tr[i0, 5], Psi0=tr[i0, 3])
+    sim.state[:, 3] = vt
+    log = {"published": [], "pubs": {}, "node": None, "sleeps": 0}
+    state = {"cb": None}
+
+    def mk(name, **fields):
+        def init(self):
+            self.header = types.SimpleNamespace(stamp=None)
+            for k, v in fields.items():
+                setattr(self, k, v)
+        return type(name, (), {"__init__": init})
+
+    msgs = types.SimpleNamespace(MPC_cmd=mk("MPC_cmd", accel_cmd=0.0, steer_angle_cmd=0.0), mpc_path=mk("mpc_path", xs=[], ys=[], psis=[]),
+                                 state_est=mk("state_est", x=0.0, y=0.0, psi=0.0, v=0.0))
+    std_msgs = types.SimpleNamespace(Empty=mk("Empty"))
+
+    class Pub:
+        def __init__(self, topic, cls, queue_size=None):
+            log["pubs"][topic] = (cls.__name__, queue_size); self.topic = topic
+        def publish(self, m):
+            log["published"].append((self.topic, m))
+            if self.topic == "mpc_cmd":                 # vehicle_simulator.py:51-55
+                sim._mpc_cmd_callback(m.accel_cmd, m.steer_angle_cmd)
+
+    class Rate:
+        def __init__(self, hz): assert hz == 10.0
+        def sleep(self):                                # 0.1 s of plant, then the next state_est (vehicle_simulator.py:40-48)
+            log["sleeps"] += 1
+            sim._update_vehicle_model(10)
+            s = sim.state_est(0)
+            m = msgs.state_est(); m.x, m.y, m.psi, m.v = s.x, s.y, s.psi, s.v
+            state["cb"](m)
+
+    params = {"mat_waypoints": "unused.mat", "track_using_time": False, "target_vel": vt}
+    rospy = types.SimpleNamespace(has_param=lambda k: k in params, get_param=lambda k, d=None: params.get(k, d),
+                                  init_node=lambda n: log.__setitem__("node", n), Publisher=Pub,
+                                  Subscriber=lambda topic, cls, cb, queue_size=None: state.__setitem__("cb", cb), Rate=Rate,
+                                  is_shutdown=lambda: False, get_rostime=lambda: 0.0)
+    mpc = KinematicMPC(N=N)
+    assert mpc.status == "Optimal" and abs(mpc.cost - 15738.467) < 1e-2    # the module-load solve (MKZMPCPathFollower.jl:125-128)
+    node = ros_node.start_mpc_node(N=N, rospy=rospy, msgs=msgs, std_msgs=std_msgs, grt=grt, mpc=mpc, max_steps=60)
+    assert log["node"] == "dbw_mpc_pf" and log["sleeps"] == 60
+    topics = [t for t, _ in log["published"]]
+    assert topics[0] == "enable" and topics.count("enable") == 1
+    body = topics[1:]
+    n_solve = body.count("target_path")
+    assert 5 <= n_solve < 59, n_solve                   # first pass idles (no state yet, :89-92); the latch comes up before the run ends
+    assert body == ["mpc_cmd", "target_path", "mpc_path"] * n_solve + ["mpc_cmd"] * (59 - n_solve)
+    assert node.command_stop
+    cmds = [(m.accel_cmd, m.steer_angle_cmd) for t, m in log["published"] if t == "mpc_cmd"]
+    solved, latched = np.array(cmds[:n_solve]), cmds[n_solve:]
+    assert np.isfinite(solved).all() and np.abs(solved[:, 0]).max() <= 1.0 + 1e-8 and np.abs(solved[:, 1]).max() <= 0.5 + 1e-8
+    assert all(c == (-1.0, 0.0) for c in latched)
+    # update_current_input(df_opt, a_opt) is steer-first (Q6): were the two swapped, the anchor of the first-step rate rows (:75-76, :82-83)
+    # would be wrong and consecutive commands would violate |d acc| <= 0.15, |d d_f| <= 0.05
+    prev = np.vstack([[0.0, 0.0], solved[:-1]])
+    assert np.abs(solved[:, 0] - prev[:, 0]).max() <= 0.15 + 1e-7 and np.abs(solved[:, 1] - prev[:, 1]).max() <= 0.05 + 1e-7
+    paths = [m for t, m in log["published"] if t == "mpc_path"]
+    assert all(len(p.xs) == N + 1 and len(p.ys) == N + 1 and len(p.psis) == N + 1 and np.isfinite(p.xs).all() for p in paths)
+    # the prediction starts at the state the solve was given (state 0 of the horizon)
+    tgt = [m for t, m in log["published"] if t == "target_path"]
+    assert all(len(p.xs) == N + 1 for p in tgt)
+    assert float(sim.state[0, 3]) < vt                  # the latched -1 m/s^2 is slowing the car down

@@ -148,6 +148,14 @@ def test_reused_output_dict_is_validated():
     o5 = s32.solve(big["z0"], big["ref"], big["v_target"], big["u_prev"], out=o4)  # other element type
     torch.cuda.synchronize()
     assert o5["u0"].dtype == torch.float32 and (o5["status"] == 0).all()
+    # the `out` of an N = 8 solver (want_U) handed to an N = 20 solver of the same batch size and element type -- U [B,8,2] would
+    # be written as [B,20,2] if the horizon were not part of the fit check
+    s20 = BatchMPC(N=20)
+    d20 = make_batch(64, 20, cfg_id=3)
+    o8 = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"], want_U=True, want_X=True)
+    o20 = s20.solve(d20["z0"], d20["ref"], d20["v_target"], d20["u_prev"], want_U=True, want_X=True, out=o8)
+    torch.cuda.synchronize()
+    assert o20["U"].shape == (64, 20, 2) and o20["X"].shape == (64, 21, 4) and (o20["status"] == 0).all() and torch.isfinite(o20["U"]).all()
 
 
 def test_batch_fp32(oracle):

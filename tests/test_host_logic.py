@@ -269,7 +269,7 @@ def test_ros_adapter_topic_surface():
     topics = [t for t, _ in log["published"]]
     assert topics == ["mpc_cmd", "target_path", "mpc_path"] * 2 + ["mpc_cmd"]
     first, last = log["published"][0][1], log["published"][-1][1]
-    assert (first.accel_cmd, first.steer_angle_cmd) == (0.3, -0.02) and first.header.stamp == 123.0
+    assert (first.accel_cmd, first.steer_angle_cmd) == (0.3, -0.02) and first.header.stamp is None   # never stamped, as in the reference (:129-132)
     assert (last.accel_cmd, last.steer_angle_cmd) == (-1.0, 0.0)
     assert ("input", (-0.02, 0.3)) in mpc.calls   # steer first (Q6)
     assert [c[0] for c in mpc.calls].count("solve") == 2
