@@ -52,7 +52,9 @@ enum {
 
 /* Replaces the module-level constants of MKZMPCPathFollower.jl:28-48 and the Ipopt options of :29. */
 typedef struct kmpc_config {
-    int32_t N;          /* horizon (:34, default 8); supported 2..56 (compile-time-horizon kernels for 8, 12, 16, 20, 24, 28) */
+    int32_t N;          /* horizon (:34, default 8); supported 2..56.  Compile-time-horizon kernels: one wave per problem for N = 8, 12,
+                           16, 20, 24, 28; one four-wave workgroup per problem for N = 32, 36, 40, 44, 48, 50; any other horizon runs the
+                           generic kernel (runtime N, matrices in LDS) */
     int32_t dtype;      /* KMPC_F64 / KMPC_F32: arithmetic AND device-buffer element type */
     double dt;          /* :33  0.20 */
     double dt_control;  /* :28  0.10 */
@@ -69,7 +71,8 @@ typedef struct kmpc_config {
     double warm_push;    /* weight of the interior point blended into a warm start (default 1e-4) */
     double warm_mu;      /* mu_init used with a warm start (default 1e-6) */
     int32_t max_ls;      /* back-tracking trial points per iteration */
-    int32_t kernel_variant; /* 0 = auto (compile-time-horizon kernel when one is built for N, else generic), 1 = generic */
+    int32_t kernel_variant; /* 0 = auto (the compile-time-horizon kernel built for N -- one-wave or four-wave, see N -- else generic),
+                               1 = always the generic kernel */
     int32_t mu_strategy;    /* barrier update: 0 = Ipopt's default monotone (Fiacco-McCormick), 1 = Mehrotra predictor-corrector
                                (Ipopt's adaptive family; default) */
     int32_t indef_strategy; /* exact Hessian not positive definite: 0 = Gauss-Newton fallback (held for 2 iterations), 1 = Ipopt-style

@@ -15,12 +15,7 @@ from ._lib import STATUS_NAMES
 from .solver import BatchMPC
 
 
-# ---- nav_msgs_path_frenet.py:12-18 --------------------------------------------------------------------------------
-def cubic_func(t, a3, a2, a1, a0): return a0 + a1 * t + a2 * t ** 2 + a3 * t ** 3
-def dcubic_func(t, a3, a2, a1, a0): return a1 + 2 * a2 * t + 3 * a3 * t ** 2
-def ddcubic_func(t, a3, a2, a1, a0): return 2 * a2 + 6 * a3 * t
-
-
+# ---- curvature-polynomial fit of nav_msgs_path_frenet.py:44-86 (numpy's polynomial helpers, coefficients highest degree first) --------
 def fit_XY_s(x_arr, y_arr, s_arr):
     """:62-73  X(s), Y(s) cubics through the waypoints resampled every 0.5 m"""
     s_interp = np.arange(s_arr[0], s_arr[-1], 0.5)
@@ -32,8 +27,9 @@ def fit_XY_s(x_arr, y_arr, s_arr):
 def compute_curvature_poly(s_interp, x_coeffs, y_coeffs):
     """:44-59  K = (x' y'' - y' x'') / (x'^2 + y'^2) on the fitted cubics, then a cubic fit of K(s), highest degree first"""
     s_interp = np.asarray(s_interp, dtype=np.float64)
-    dx, dy = dcubic_func(s_interp, *x_coeffs), dcubic_func(s_interp, *y_coeffs)
-    ddx, ddy = ddcubic_func(s_interp, *x_coeffs), ddcubic_func(s_interp, *y_coeffs)
+    d1x, d1y = np.polyder(x_coeffs), np.polyder(y_coeffs)
+    dx, dy = np.polyval(d1x, s_interp), np.polyval(d1y, s_interp)
+    ddx, ddy = np.polyval(np.polyder(d1x), s_interp), np.polyval(np.polyder(d1y), s_interp)
     K_meas = (dx * ddy - dy * ddx) / (dx ** 2 + dy ** 2)
     return np.polyfit(s_interp, K_meas, 3)
 
@@ -42,10 +38,10 @@ def get_reference_frenet(path):
     """:76-86  path = dict(x, y, s) -> (K_coeffs, psi_start, x_interp, y_interp)"""
     x_coeffs, y_coeffs = fit_XY_s(path["x"], path["y"], path["s"])
     s_interp = np.arange(0.0, path["s"][-1], 0.25)
-    x_interp = cubic_func(s_interp, *x_coeffs)
-    y_interp = cubic_func(s_interp, *y_coeffs)
+    x_interp = np.polyval(x_coeffs, s_interp)
+    y_interp = np.polyval(y_coeffs, s_interp)
     K_coeffs = compute_curvature_poly(s_interp, x_coeffs, y_coeffs)
-    psi_start = math.atan2(dcubic_func(0.0, *y_coeffs), dcubic_func(0.0, *x_coeffs))
+    psi_start = math.atan2(y_coeffs[2], x_coeffs[2])   # slopes of the two cubics at s = 0
     return K_coeffs, psi_start, x_interp, y_interp
 
 

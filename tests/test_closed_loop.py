@@ -223,7 +223,7 @@ def test_ros_adapter_drives_the_real_solver():
     N, vt = 8, 6.0
     grt = GPSRefTrajectory(arrays=_path_arrays(), traj_horizon=N, traj_dt=0.2)
     tr = grt.get_global_trajectory_reference()
-    i0 = len(tr) - 90                                   # ~20 m before the end of the path: the stop flag comes up within the run
+    i0 = int(np.searchsorted(tr[:, 6], tr[-1, 6] - 25.0))   # 25 m before the end of the path (look-ahead 10.8 m at 6 m/s): the stop flag comes up within the run
     sim = VehicleSimulator(1, X0=tr[i0, 4], Y0=tr[i0, 5], Psi0=tr[i0, 3])
     sim.state[:, 3] = vt
     log = {"published": [], "pubs": {}, "node": None, "sleeps": 0}

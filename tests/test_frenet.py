@@ -81,7 +81,7 @@ def test_frenet_oracle_vs_scipy(oracle):
 def test_curvature_polynomial_fit_recovers_a_known_curvature():
     """nav_msgs_path_frenet.py:44-86 restated: waypoints on a clothoid-like path with K(s) = 0.01 + 0.002 s are fitted back to a
     polynomial whose curvature matches over the fitted range (the double cubic fit is approximate by construction)"""
-    from mkz_mpc_path_follower_amd.kinematic_mpc_frenet import get_reference_frenet, cubic_func
+    from mkz_mpc_path_follower_amd.kinematic_mpc_frenet import get_reference_frenet
     s = np.arange(0.0, 30.0, 0.05)
     K = 0.01 + 0.002 * s
     psi = 0.3 + np.concatenate([[0.0], np.cumsum(0.5 * (K[1:] + K[:-1]) * np.diff(s))])
@@ -90,7 +90,7 @@ def test_curvature_polynomial_fit_recovers_a_known_curvature():
     Kc, psi0, xi, yi = get_reference_frenet(dict(x=x[::20], y=y[::20], s=s[::20]))
     assert abs(psi0 - 0.3) < 0.05
     sm = np.linspace(3.0, 25.0, 12)
-    assert np.abs(cubic_func(sm, *Kc) - (0.01 + 0.002 * sm)).max() < 0.01
+    assert np.abs(np.polyval(Kc, sm) - (0.01 + 0.002 * sm)).max() < 0.01
     assert np.hypot(xi - np.interp(np.arange(0.0, s[::20][-1], 0.25), s, x), yi - np.interp(np.arange(0.0, s[::20][-1], 0.25), s, y)).max() < 0.2
 
 
