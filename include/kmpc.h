@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KMPC_ABI_VERSION 6
+#define KMPC_ABI_VERSION 7
 
 /* per-problem status, replaces the Symbol returned by solve_model() (MKZMPCPathFollower.jl:176,182) */
 enum {
@@ -53,8 +53,9 @@ enum {
 /* Replaces the module-level constants of MKZMPCPathFollower.jl:28-48 and the Ipopt options of :29. */
 typedef struct kmpc_config {
     int32_t N;          /* horizon (:34, default 8); supported 2..56.  Compile-time-horizon kernels: one wave per problem for N = 8, 12,
-                           16, 20, 24, 28; one four-wave workgroup per problem for N = 32, 36, 40, 44, 48, 50; any other horizon runs the
-                           generic kernel (runtime N, matrices in LDS) */
+                           16, 20, 24, 28 (N = 8, the reference's own horizon, also FOUR problems per wave: one per 16-lane row); one
+                           four-wave workgroup per problem for N = 32, 36, 40, 44, 48, 50; any other horizon runs the generic kernel
+                           (runtime N, matrices in LDS) */
     int32_t dtype;      /* KMPC_F64 / KMPC_F32: arithmetic AND device-buffer element type */
     double dt;          /* :33  0.20 */
     double dt_control;  /* :28  0.10 */
@@ -71,8 +72,9 @@ typedef struct kmpc_config {
     double warm_push;    /* weight of the interior point blended into a warm start (default 1e-4) */
     double warm_mu;      /* mu_init used with a warm start (default 1e-6) */
     int32_t max_ls;      /* back-tracking trial points per iteration */
-    int32_t kernel_variant; /* 0 = auto (the compile-time-horizon kernel built for N -- one-wave or four-wave, see N -- else generic),
-                               1 = always the generic kernel */
+    int32_t kernel_variant; /* 0 = auto: the compile-time-horizon kernel built for N (see N; at N = 8 batches of 1024 problems or more run the
+                               four-problems-per-wave kernel), else the generic one; 1 = always the generic kernel; 2 = as 0 but never the
+                               four-per-wave kernel (one wave / one workgroup per problem at every batch size) */
     int32_t mu_strategy;    /* barrier update: 0 = Ipopt's default monotone (Fiacco-McCormick), 1 = Mehrotra predictor-corrector
                                (Ipopt's adaptive family; default) */
     int32_t indef_strategy; /* exact Hessian not positive definite: 0 = Gauss-Newton fallback (held for 2 iterations), 1 = Ipopt-style
@@ -86,6 +88,11 @@ typedef struct kmpc_config {
                                Frenet-frame states (s, e_y, e_psi, v) with a cubic curvature polynomial (kmpc_solve_batch_frenet;
                                horizons N <= 24, and N = 28 with kernel_variant 0: the compile-time-horizon kernels carry the functor
                                for N = 8, 12, ..., 28).  kmpc_create picks the cost defaults of the chosen module. */
+    int32_t start;          /* cold-start point of the inputs (a warm start overrides it): 0 (default) = feed-forward guess inside the bounds
+                               (accelerations approach the reference speed, steering the curvature feed-forward); 1 = the reference's own
+                               start, every primal 0 (MKZMPCPathFollower.jl:65-72, Q9), moved strictly inside the first-step rate interval
+                               around u_prev and the speed rows where 0 is not.  The program is non-convex: the two may end in different
+                               local minima on a few problems per thousand (tests/test_certify.py counts them). */
 } kmpc_config;
 
 typedef struct kmpc_handle kmpc_handle;

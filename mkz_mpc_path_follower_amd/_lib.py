@@ -22,7 +22,8 @@ class Config(C.Structure):
                 ("max_iter", C.c_int32), ("hessian", C.c_int32), ("tol", C.c_double),
                 ("mu_init", C.c_double), ("bound_relax", C.c_double), ("warm_push", C.c_double),
                 ("warm_mu", C.c_double), ("max_ls", C.c_int32), ("kernel_variant", C.c_int32),
-                ("mu_strategy", C.c_int32), ("indef_strategy", C.c_int32), ("schedule", C.c_int32), ("model", C.c_int32)]
+                ("mu_strategy", C.c_int32), ("indef_strategy", C.c_int32), ("schedule", C.c_int32), ("model", C.c_int32),
+                ("start", C.c_int32)]
 
 
 EXPORTS = ["kmpc_abi_version", "kmpc_config_default", "kmpc_create", "kmpc_destroy", "kmpc_set_cost",

@@ -19,6 +19,8 @@ template <typename T> bool kmpc_fast_available(int N);
 template <typename T> hipError_t kmpc_launch_solve_fast(const KP &, const KIO<T> &, hipStream_t);
 template <typename T> bool kmpc_wide_available(int N);
 template <typename T> hipError_t kmpc_launch_solve_wide(const KP &, const KIO<T> &, hipStream_t);
+template <typename T> bool kmpc_quad_available(int N);
+template <typename T> hipError_t kmpc_launch_solve_quad(const KP &, const KIO<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_solve_frenet(const KP &, const KIO<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_solve_fast_frenet(const KP &, const KIO<T> &, hipStream_t);
 template <typename T> hipError_t kmpc_launch_fast_kkt(const KP &, const KDbgK<T> &, hipStream_t);
@@ -26,6 +28,10 @@ template <typename T> hipError_t kmpc_launch_wide_kkt(const KP &, const KDbgK<T>
 hipError_t kmpc_launch_sim(int, double *, const double *, int, hipStream_t);
 hipError_t kmpc_launch_command(int, const double *, const int32_t *, uint8_t *, double *, double *, hipStream_t);
 template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, const T *, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
+
+#ifndef KMPC_QUAD_MIN_BATCH
+#define KMPC_QUAD_MIN_BATCH 1024   // below this the one-wave-per-problem kernel's shorter single-solve latency wins (measured: tools/quad_probe.py)
+#endif
 
 struct kmpc_handle {
     kmpc_config cfg;
@@ -97,6 +103,7 @@ extern "C" int32_t kmpc_config_default(kmpc_config *c, int32_t N, int32_t dtype)
     c->schedule = 1;  // longest-predicted-first start order (kmpc_schedule.hip)
     c->model = 0;
     c->mu_strategy = 1;  // Mehrotra predictor-corrector (all Optimal on seeded draws at N = 8 ... 56; a third fewer iterations than the monotone rule)
+    c->start = 0;        // feed-forward start (1 = the reference's all-zero start, MKZMPCPathFollower.jl:65-72)
     return KMPC_OK;
 }
 
@@ -108,9 +115,10 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
     if (!(cfg->dt > 0) || !(cfg->dt_control > 0) || !(cfg->L_b > 0) || !(cfg->L_a + cfg->L_b > 0) ||
         !(cfg->v_max > cfg->v_min) || !(cfg->a_max > 0) || !(cfg->steer_max > 0) || !(cfg->steer_max < 1.5) ||
         !(cfg->a_dmax > 0) || !(cfg->steer_dmax > 0) || cfg->max_iter < 1 || cfg->max_ls < 1 || !(cfg->tol > 0) ||
-        cfg->kernel_variant < 0 || cfg->kernel_variant > 1 || cfg->mu_strategy < 0 || cfg->mu_strategy > 1 ||
+        cfg->kernel_variant < 0 || cfg->kernel_variant > 2 || cfg->mu_strategy < 0 || cfg->mu_strategy > 1 ||
         cfg->indef_strategy < 0 || cfg->indef_strategy > 2 || cfg->schedule < 0 || cfg->schedule > 1 || cfg->model < 0 || cfg->model > 1 ||
-        (cfg->model == 1 && cfg->N > 24 && !(cfg->kernel_variant == 0 && cfg->N == 28)))  // Frenet: generic kernel up to N = 24, compile-time kernel also at 28
+        cfg->start < 0 || cfg->start > 1 ||
+        (cfg->model == 1 && cfg->N > 24 && !(cfg->kernel_variant != 1 && cfg->N == 28)))  // Frenet: generic kernel up to N = 24, compile-time kernel also at 28
         return fail(nullptr, KMPC_ERR_ARG, "kmpc_create: invalid model / solver parameter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KMPC_ERR_NODEVICE, "kmpc_create: no HIP device");
@@ -176,12 +184,13 @@ static KP make_kp(const kmpc_handle *h, int B, int warm, int hessian_override)
     P.N = c.N; P.B = B; P.max_iter = c.max_iter;
     P.hessian = hessian_override >= 0 ? hessian_override : c.hessian;
     P.warm = warm; P.max_ls = c.max_ls; P.mu_strategy = c.mu_strategy; P.indef_strategy = c.indef_strategy;
+    P.start = c.start;
     P.dt = c.dt; P.dtc = c.dt_control; P.L_b = c.L_b; P.r = c.L_b / (c.L_a + c.L_b);
     P.steer_max = c.steer_max; P.steer_dmax = c.steer_dmax; P.a_max = c.a_max; P.a_dmax = c.a_dmax;
     P.v_min = c.v_min; P.v_max = c.v_max;
     memcpy(P.C, h->cost, sizeof P.C);
     P.tol = c.tol; P.mu_init = c.mu_init; P.relax = c.bound_relax; P.warm_push = c.warm_push; P.warm_mu = c.warm_mu;
-    P.gap_tol = c.dtype == KMPC_F32 ? 1e-4 : 1e-7;
+    P.gap_tol = c.dtype == KMPC_F32 ? 1e-4 : 1e-7;  // unscaled duality-gap bound relative to max(1, |J|)
     for (int i = 0; i < 8; ++i) P.C2[i] = 2.0 * P.C[i];
     P.dt2 = P.dt * P.dt; P.dt_over_Lb = P.dt / P.L_b;
     P.tol_x100 = 100.0 * P.tol; P.tol_x1000 = 1e3 * P.tol; P.tol_d100 = P.tol * 1e-2; P.tol_d10 = P.tol / 10.0;
@@ -202,7 +211,7 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
     io.perm = nullptr;
     // start order: only matters once a launch no longer fits on the chip at once (2 waves x 4 SIMDs x 256 CUs)
     if (h->cfg.model == 1) {  // Frenet functor: `ref` carries k_poly [B,4]; index order (the start-order key reads reference points)
-        if (h->cfg.kernel_variant == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast_frenet<T>(P, io, st));
+        if (h->cfg.kernel_variant != 1 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast_frenet<T>(P, io, st));
         else HIPCHK(h, kmpc_launch_solve_frenet<T>(P, io, st));   // generic kernel: N <= 24
         return KMPC_OK;
     }
@@ -226,8 +235,10 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
         h->sched_parity ^= 1;
         io.perm = h->perm;
     }
-    if (h->cfg.kernel_variant == 0 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));        // one wave per problem
-    else if (h->cfg.kernel_variant == 0 && kmpc_wide_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_wide<T>(P, io, st));  // four waves per problem
+    // N = 8 (the reference's own horizon): four problems per wave once a batch has enough problems to fill the chip that way
+    if (h->cfg.kernel_variant == 0 && kmpc_quad_available<T>(P.N) && B >= KMPC_QUAD_MIN_BATCH) HIPCHK(h, kmpc_launch_solve_quad<T>(P, io, st));
+    else if (h->cfg.kernel_variant != 1 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast<T>(P, io, st));   // one wave per problem
+    else if (h->cfg.kernel_variant != 1 && kmpc_wide_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_wide<T>(P, io, st));  // four waves per problem
     else HIPCHK(h, kmpc_launch_solve<T>(P, io, st));
     return KMPC_OK;
 }

@@ -9,6 +9,20 @@
 
 #define DEV __device__ __forceinline__
 
+// Tuned constants of the non-convex phase (kmpc_ipm.h and the generic kernel; the CPU checker carries the same values).  Chosen on the
+// pooled worst-of-4096 statistics of 48 seeded 4096-problem batches: shift growth after a failed first trial
+// 8 -> 3 (the first trial is last/3, so x3 returns to the shift that worked last iteration instead of overshooting it 2.7-fold),
+// barrier floor in shifted iterations rd/1000 -> rd/100.
+#ifndef KMPC_IKRD
+#define KMPC_IKRD 1e-3
+#endif
+#ifndef KMPC_IKRD_NC
+#define KMPC_IKRD_NC 1e-2
+#endif
+#ifndef KMPC_DW_GROW
+#define KMPC_DW_GROW 3
+#endif
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
@@ -57,24 +71,28 @@ template <typename T> DEV T scan_suffix(T x, int lane) {  // inclusive, lane 63 
 
 // phase stamps: diagnostic builds only (-DKMPC_STAMPS); the shipped library has none.  -DKMPC_TRACE (diagnostic too) turns the
 // stamp buffer into a per-iteration record of one problem: row `it` = 8 doubles (tools/trace_problem.py)
+// (X_AT(obj, ..) are the forms the shared code of kmpc_ipm.h uses on the solver object; inside the solver structs STAMP(i) = STAMP_AT(*this, i))
 #ifdef KMPC_TRACE
 #define STAMP_MEMBERS
-#define STAMP_DECL
-#define STAMP(i)
-#define STAMP_OUT(ptr, b)
+#define STAMP_DECL_AT(o)
+#define STAMP_AT(o, i)
+#define STAMP_OUT_AT(o, ptr, b)
 #define TRACE8(ptr, it, a0, a1, a2, a3, a4, a5, a6, a7) do { if ((ptr) && threadIdx.x == 0 && (it) < 256) { double *q_ = (double *)(ptr) + 8 * (it); \
     q_[0] = (double)(a0); q_[1] = (double)(a1); q_[2] = (double)(a2); q_[3] = (double)(a3); q_[4] = (double)(a4); q_[5] = (double)(a5); q_[6] = (double)(a6); q_[7] = (double)(a7); } } while (0)
 #elif defined(KMPC_STAMPS)
 #define STAMP_MEMBERS unsigned long long st_t0_, st_acc_[16];
-#define STAMP_DECL do { st_t0_ = __builtin_readcyclecounter(); for (int i_ = 0; i_ < 16; ++i_) st_acc_[i_] = 0; } while (0);
-#define STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc_[i] += t_ - st_t0_; st_t0_ = t_; } while (0)
-#define STAMP_OUT(ptr, b) do { if ((ptr) && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) (ptr)[(size_t)(b) * 16 + i_] = st_acc_[i_]; } while (0)
+#define STAMP_DECL_AT(o) do { (o).st_t0_ = __builtin_readcyclecounter(); for (int i_ = 0; i_ < 16; ++i_) (o).st_acc_[i_] = 0; } while (0);
+#define STAMP_AT(o, i) do { unsigned long long t_ = __builtin_readcyclecounter(); (o).st_acc_[i] += t_ - (o).st_t0_; (o).st_t0_ = t_; } while (0)
+#define STAMP_OUT_AT(o, ptr, b) do { if ((ptr) && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) (ptr)[(size_t)(b) * 16 + i_] = (o).st_acc_[i_]; } while (0)
 #else
 #define STAMP_MEMBERS
-#define STAMP_DECL
-#define STAMP(i)
-#define STAMP_OUT(ptr, b)
+#define STAMP_DECL_AT(o)
+#define STAMP_AT(o, i)
+#define STAMP_OUT_AT(o, ptr, b)
 #endif
+#define STAMP_DECL STAMP_DECL_AT(*this)
+#define STAMP(i) STAMP_AT(*this, i)
+#define STAMP_OUT(ptr, b) STAMP_OUT_AT(*this, ptr, b)
 #ifndef TRACE8
 #define TRACE8(ptr, it, a0, a1, a2, a3, a4, a5, a6, a7)
 #endif

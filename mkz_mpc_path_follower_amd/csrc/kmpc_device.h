@@ -6,6 +6,7 @@
 // model + solver parameters, passed to kernels by value
 struct KP {
     int N, B, max_iter, hessian, warm, max_ls, mu_strategy, indef_strategy;
+    int start;  // start point: 0 feed-forward, 1 the reference's all-zero start (kmpc_ipm.h)
     double dt, dtc, L_b, r;  // r = L_b / (L_a + L_b)  (MKZMPCPathFollower.jl:115)
     double steer_max, steer_dmax, a_max, a_dmax, v_min, v_max;
     double C[8];  // update_cost order: C_x, C_y, C_psi, C_v, C_dacc, C_ddf, C_acc, C_df

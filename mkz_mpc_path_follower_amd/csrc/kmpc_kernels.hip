@@ -795,8 +795,9 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         if (MODEL == 1) kap = ((kp0 * x0 + kp1) * x0 + kp2) * x0 + kp3;  // Frenet: curvature of the polynomial at s0
         const T vref = MODEL == 1 ? vt : len / ((T)(N - 1) * dt);
         const T sb = fmin(fmax((T)P.L_b * kap, (T)-0.9), (T)0.9);
-        const T dff = fmin(fmax(atan(sb / sqrt((T)1 - sb * sb) / rr)  /* tan(asin(sb)) = sb / sqrt(1 - sb^2), |sb| <= 0.9 */, -frac * (T)P.steer_max), frac * (T)P.steer_max);
-        const T aff = fmin(fmax(vref - v0, -frac * (T)P.a_max), frac * (T)P.a_max);
+        const T ffw = P.start == 1 ? (T)0 : (T)1;  // start = 1: the reference's all-zero start (MKZMPCPathFollower.jl:65-72), no feed-forward (kmpc_ipm.h)
+        const T dff = ffw * fmin(fmax(atan(sb / sqrt((T)1 - sb * sb) / rr)  /* tan(asin(sb)) = sb / sqrt(1 - sb^2), |sb| <= 0.9 */, -frac * (T)P.steer_max), frac * (T)P.steer_max);
+        const T aff = ffw * fmin(fmax(vref - v0, -frac * (T)P.a_max), frac * (T)P.a_max);
         T u0[2];
         // Q5: v[1] = v0 is itself bounded in the reference model -> any v0 outside the (relaxed) speed bounds is infeasible
         bool ok = v0 >= (T)P.v_min - relax * fmax((T)1, fabs((T)P.v_min)) && v0 <= (T)P.v_max + relax * fmax((T)1, fabs((T)P.v_max));
@@ -823,7 +824,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         if (lane == 0) Uf[0] = u0[0];
         if (lane == 1) Uf[0] = u0[1];
         for (int k = 1; k < N; ++k) {  // uniform scalar recurrence, N steps
-            T a = fmin(fmax(vref - v, -frac * (T)P.a_max), frac * (T)P.a_max);
+            T a = ffw * fmin(fmax(vref - v, -frac * (T)P.a_max), frac * (T)P.a_max);
             a = fmin(fmax(a, ap - astep), ap + astep);
             if (v + dt * a < (T)P.v_min + vm) a = fmin((T)P.v_min + vm - v, acap);
             else if (v + dt * a > (T)P.v_max - vm) a = fmax((T)P.v_max - vm - v, -acap);
@@ -1004,7 +1005,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                     if (LDSACC) need_condense = true;  // the tiles lived in the matrix the factorisation just overwrote
                     if (use_exact && indef == 1) {
                         if (reg == 0) reg = dw_last > 0 ? fmax((T)1e-10 * hmax, dw_last / 3) : (T)1e-2 * hmax;
-                        else reg *= dw_last > 0 ? (T)8 : (T)10;
+                        else reg *= dw_last > 0 ? (T)KMPC_DW_GROW : (T)10;
                         if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; need_condense = true; }
                     } else if (use_exact) {  // drop the second-order term
                         use_exact = false; gn_hold = 2; need_condense = true;
@@ -1047,7 +1048,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                     mucur = wave_sum(mucur) / (T)(2 * nf); muaff = wave_sum(muaff) / (T)(2 * nf);
                     const T r3 = muaff / mucur;
                     mu = fmax(mu_min, fmin((T)1, r3 * r3 * r3) * mucur);
-                    mu = fmax(mu, fmin(mucur, rdm / s_d / (T)1e3));  // no barrier target far below the dual infeasibility
+                    mu = fmax(mu, fmin(mucur, rdm / s_d * ((use_exact && reg > 0) ? (T)KMPC_IKRD_NC : (T)KMPC_IKRD)));  // no barrier target far below the dual infeasibility (kmpc_ipm.h)
                 }
                 const T tau = fmax(tau_min, (T)1 - mu);
                 T ad = 1, Jt = 0, alpha_acc = 0;

@@ -1,0 +1,236 @@
+// kmpc_quad.hip -- FOUR PROBLEMS PER WAVEFRONT at the reference's own horizon N = 8 (MKZMPCPathFollower.jl:34, mpc_cmd_pub.jl:51), gfx950 only.
+//
+// At N = 8 the condensed problem has n = 16 inputs, 38 linear forms and 9 stages: the one-wave-per-problem kernel (kmpc_fast.hip) keeps 17 of
+// its 64 lanes busy.  Here a 16-lane DPP ROW is one problem: lane r of a row holds input r, forms r, r + 16, r + 32 and stage r.
+//   * The model code and the interior-point state machine are the shared ones (kmpc_ipm.h) with NTH = 16 "threads per problem": the stage
+//     scans (row_shr / row_shl steps) never leave a row, every LDS buffer is per row, and what the one-wave kernels keep as wave-uniform
+//     scalars (mode, mu, alpha, iteration counters, ...) are per-row values here -- the rows of a wave branch independently (a row whose
+//     line search back-tracks or whose factorisation is repeated runs that path under its own exec mask; a finished row idles until the
+//     wave's last row is done).  The start order (kmpc_schedule.hip) puts problems of similar predicted difficulty into one wave.
+//   * Reductions are row-local butterflies on DPP row rotations (row_ror 8, 4, 2, 1): every lane of the row ends with bit-identical
+//     results (each level adds the same two partial sums in either order), which is what keeps a row's 16 lanes on one control path.
+//   * KKT: the 16 x 16 matrix is one row (i) per lane, in registers; Cholesky is 16 right-looking column steps whose only exchange is one
+//     per-row LDS all-gather of the pivot column; the right-hand side -sc*g rides along (forward substitution inside the factorisation).
+//     The substitutions are 16 dependent steps each (forward on the lane's row of L, backward on its column, fetched once through the
+//     packed image); at this size the matrix cores have nothing to offer -- a trailing update is n^3/3 = 1.4 k flops per problem.
+// Results agree with the one-wave kernel to rounding (different summation trees), not bit for bit: tests/test_quad.py.
+#include "kmpc_ipm.h"
+
+template <typename T> DEV T row_sum(T x) {   // sum over the 16 lanes of a DPP row, identical bits in every lane
+    x += dpp_mov0<0x128, 0xf>(x); x += dpp_mov0<0x124, 0xf>(x); x += dpp_mov0<0x122, 0xf>(x); x += dpp_mov0<0x121, 0xf>(x);
+    return x;
+}
+template <typename T> DEV T row_max(T x) {   // maximum over the row (any sign; NaN operands dropped as by fmax)
+    x = max_raw(x, dpp_mov0<0x128, 0xf>(x)); x = max_raw(x, dpp_mov0<0x124, 0xf>(x));
+    x = max_raw(x, dpp_mov0<0x122, 0xf>(x)); x = max_raw(x, dpp_mov0<0x121, 0xf>(x));
+    return x;
+}
+
+template <typename T> struct QuadSolver {
+    static constexpr int N = 8;
+    KMPC_HORIZON_CONSTANTS(8)
+    typedef T real;
+    // what kmpc_ipm.h reads: horizon, threads per problem, forms per thread, stride of the G_N table, record stride, functor
+    static constexpr int N_ = 8, NTH = 16, NF = 3, GS = 16, LSTR = 16, MODEL_ID = 0;
+    static_assert(n == 16 && nf <= 48, "one DPP row per problem");
+    // per-row LDS map (elements of T)
+    static constexpr int O_LC = 0, O_XB = (LC + 1) & ~1, O_WB = O_XB + 16, O_CB = O_WB + 48, O_LIN = O_CB + 16, O_GNB = O_LIN + LSTR * (N + 1),
+                         O_GB = O_GNB + 3 * GS, O_CS = O_GB + 16, O_UB = O_CS + 16, O_CU = O_UB + 16, O_CL = O_CU + 48, O_EX = O_CL + 48,
+                         ROW = O_EX + 32;
+    static constexpr int O_PT = 4 * ROW, O_KC = O_PT + 32;
+    static constexpr int lds_elems() { return O_KC + (sizeof(T) == 8 ? KC_COUNT : 0); }
+
+    STAMP_MEMBERS
+    const KP &P;
+    int lane, vid, row;   // lane = vid = position in the row (stage / input / first form slot), row = which of the wave's four problems
+    T *Lc, *xb, *wb, *cb, *lin, *gnb, *gb, *cs, *ubest, *cub, *clb, *ex;
+    const T *pt, *cwt;
+    Coef<T> kc;
+    T psi0, v0, vt, up0, up1, rx, ry, rp, xoff_, yoff_;
+    T rd;      // 1 / L[lane][lane]
+    T yv;      // (L^-1 (-sc g))[lane]
+
+    DEV QuadSolver(const KP &p, unsigned char *smem) : P(p), lane(threadIdx.x & 15), vid(threadIdx.x & 15), row(threadIdx.x >> 4)
+    {
+        T *base = reinterpret_cast<T *>(smem);
+        T *rb = base + ROW * row;
+        Lc = rb + O_LC; xb = rb + O_XB; wb = rb + O_WB; cb = rb + O_CB; lin = rb + O_LIN; gnb = rb + O_GNB; gb = rb + O_GB; cs = rb + O_CS;
+        ubest = rb + O_UB; cub = rb + O_CU; clb = rb + O_CL; ex = rb + O_EX;
+        kc.tab = base + O_KC;
+        if (sizeof(T) == 8 && threadIdx.x < KC_COUNT) const_cast<T *>(kc.tab)[threadIdx.x] = (T)kmpc_coef[threadIdx.x];
+        pt = base + O_PT; cwt = pt + PT_W;
+        if (threadIdx.x == 0) ipm::fill_param_table(base + O_PT, p, nf);
+        WSYNC();
+    }
+
+    DEV void load_problem(const T *z0, const T *ref, const T *vtp, const T *upp, int b)   // b: this row's problem
+    {
+        // vehicle-centred coordinates (the NLP is translation-invariant; see kmpc_fast.hip)
+        xoff_ = z0[4 * (size_t)b]; yoff_ = z0[4 * (size_t)b + 1];
+        psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
+        vt = vtp[b];
+        up0 = upp[2 * (size_t)b]; up1 = upp[2 * (size_t)b + 1];
+        rx = ry = rp = (T)0;
+        if (lane <= N) {
+            const T *r = ref + ((size_t)b * (N + 1) + lane) * 3;
+            rx = r[0] - xoff_; ry = r[1] - yoff_; rp = r[2];
+        }
+    }
+
+    // ---- hooks of the shared interior-point code (kmpc_ipm.h) ------------------------------------------------------------------------
+    DEV T up(int j) const { return j ? up1 : up0; }
+    DEV T xoff() const { return xoff_; }
+    DEV T yoff() const { return yoff_; }
+    DEV bool rec_writer() const { return true; }
+    DEV void refresh_ids() { asm volatile("" : "+v"(lane)); vid = lane; }
+    DEV T &cu(int i) { return cub[lane + 16 * i]; }
+    DEV T &cl(int i) { return clb[lane + 16 * i]; }
+    DEV void save_best(T U) { ubest[lane] = U; }
+    DEV T load_best() const { return ubest[lane]; }
+    template <int NS, int NM> DEV void reduce(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM])
+    {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sm[i] = row_sum(sm[i]);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) mx[i] = row_max(mx[i]);
+    }
+    template <int NS, int NM> DEV void reduce_flag(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM], bool &all_true)
+    {
+        all_true = row_max(all_true ? (T)0 : (T)1) == (T)0;
+        reduce<NS, NM>(sm, mx);
+    }
+    DEV T max_any(T x) const { return row_max(x); }
+    DEV T sum_stages(T x) const { return row_sum(x); }
+    DEV T stage_bcast(T x, int k)   // value of the row's lane k (start-up only: through the row's exchange buffer)
+    {
+        ex[lane] = x;
+        WFENCE();
+        const T v = ex[k];
+        WFENCE();
+        return v;
+    }
+    DEV void stage_form_weights(const T (&w)[NF]) { ipm::stage_form_weights(*this, w); }
+    DEV bool interior_point(T &Uf) { return ipm::interior_point(*this, Uf); }
+    DEV T eval(T U, StageV<T> &S) { return ipm::eval_cartesian(*this, U, S); }
+    DEV T linearize(const StageV<T> &S, bool exact) { return ipm::linearize_cartesian(*this, S, exact); }
+    DEV void drop_second_order() { ipm::drop_second_order_cartesian(*this); }
+
+    // ---- KKT: K = sc*(H + input Hessian) + A^T W A + reg*I, one row per lane, Cholesky + the affine right-hand side in one sweep ------------
+    // (needs stage_form_weights(w) done: wb = form weights, cb = suffix sums of the speed weights)
+    DEV bool kkt_factor(T sc, T reg, bool want_hmax)
+    {
+        ipm::condense_adjoint(*this, sc);   // column j (rows >= j) of sc*H into the row's packed image
+        if (want_hmax) cs[C_HMAX] = row_max(fabs(Lc[offc_rt(lane) + lane]));   // max |sc * H_jj|: scale of the delta_w shift
+        T *dgs = cub, *sbs = clb;   // the corrector buffers are dead between the accepted step and the end of the factorisation
+        ipm::kkt_diag_staging(*this, sc, reg, true, dgs, sbs);
+        const int i = lane;
+        T a[16];   // row i of the KKT matrix, then of its Cholesky factor L (registers only while the factorisation runs)
+        const T dt2 = pt[PT_DT2];
+        const T spd = (i & 1) ? (T)0 : dt2 * cb[i >> 1];   // speed rows: dt^2 * S[max(i,k)/2] on the (even, even) entries; max = i in the lower triangle
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            T v = (T)0;
+            if (k <= i) {
+                v = Lc[offc(k) + i];
+                if (!(k & 1)) v += spd;
+                if (k == i) v += dgs[k];
+                if (k == i - 2) v += sbs[k];
+            }
+            a[k] = v;
+        }
+        T b = -sc * gb[i];
+        WFENCE();   // image, dgs / sbs consumed: the exchange buffer and (later) the image may be overwritten
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            ex[i] = a[j];        // column j of the current Schur complement (rows < j: stale values nobody reads)
+            ex[16 + i] = b;
+            WFENCE();
+            const T d = ex[j];
+            ok = ok && d > Real<T>::tiny() && d < (T)1e300;
+            const T rinv = rsqrt_(d);
+            const T lij = a[j] * rinv;          // L[i][j] (i >= j; L[j][j] = d * rinv = sqrt(d))
+            const T yj = ex[16 + j] * rinv;     // y_j = b_j / L[j][j]
+            const T t = lij * rinv;             // a[k] -= L[i][j] L[k][j] = t * colbuf[k]
+#pragma unroll
+            for (int k = j + 1; k < 16; ++k) a[k] = fma(-t, ex[k], a[k]);   // (entries k > i are never used)
+            b = i > j ? fma(-lij, yj, b) : (i == j ? yj : b);   // rows above j hold finished components of y
+            a[j] = lij;
+            if (i == j) rd = rinv;
+            WFENCE();
+        }
+        yv = b;
+        // L goes to the row's packed image (sc*H there is dead; a refactorisation re-condenses): the substitutions read the lane's row
+        // (forward) and column (backward) of it from there instead of holding 32 more registers across the whole iteration
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k <= i) Lc[offc(k) + i] = a[k];
+        WFENCE();
+        return ok;   // (not positive definite: NaNs may have been produced above; nothing is used in that case)
+    }
+    DEV T back_subst(T z) const   // L^T x = z
+    {
+        T *xe = ex;
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            const T xi_c = z * rd;
+            if (lane == i) xe[i] = xi_c;
+            WFENCE();
+            const T xi = xe[i];
+            const T lij = lane < i ? Lc[offc_rt(lane) + i] : (T)0;   // L[i][lane]: column `lane` of L; lanes > i hold finished components
+            z = lane == i ? xi : fma(-lij, xi, z);
+        }
+        WFENCE();
+        return z;
+    }
+    DEV T fwd_subst(T b) const    // L w = b
+    {
+        T *xe = ex + 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const T wj_c = b * rd;
+            if (lane == j) xe[j] = wj_c;
+            WFENCE();
+            const T wj = xe[j];
+            const T lij = lane > j ? Lc[offc(j) + lane] : (T)0;       // L[lane][j]: row `lane` of L
+            b = lane == j ? wj : fma(-lij, wj, b);
+        }
+        WFENCE();
+        return b;
+    }
+    DEV T kkt_affine() { return back_subst(yv); }                           // K^-1 (-sc g)
+    DEV T kkt_direction(T b) { return back_subst(yv + fwd_subst(b)); }      // K^-1 (-sc g + b)
+
+    DEV void solve(const KIO<T> &io, int b) { ipm::solve(*this, io, b); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : 4) void kmpc_solve_quad_kernel(KP P, KIO<T> io)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[QuadSolver<T>::lds_elems() * sizeof(T)];
+    const int slot = 4 * (int)blockIdx.x + ((int)threadIdx.x >> 4);
+    if (4 * (int)blockIdx.x >= P.B) return;
+    // a wave's four rows take four consecutive entries of the start order (similar predicted difficulty); the rows past the end of a batch
+    // whose size is not a multiple of four repeat its last problem (same inputs, same stores)
+    const int sl = slot < P.B ? slot : P.B - 1;
+    const int b = io.perm ? io.perm[sl] : sl;
+#ifdef KMPC_POISON
+    for (int e = threadIdx.x; e < QuadSolver<T>::lds_elems(); e += 64) reinterpret_cast<T *>(smem)[e] = (T)NAN;
+    __syncthreads();
+#endif
+    QuadSolver<T> sv(P, smem);
+    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
+    sv.solve(io, b);
+}
+
+template <typename T> bool kmpc_quad_available(int N) { return N == 8; }
+template <typename T> hipError_t kmpc_launch_solve_quad(const KP &P, const KIO<T> &io, hipStream_t st)
+{
+    if (P.N != 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((kmpc_solve_quad_kernel<T>), dim3((P.B + 3) / 4), dim3(64), 0, st, P, io);
+    return hipGetLastError();
+}
+template bool kmpc_quad_available<double>(int);
+template bool kmpc_quad_available<float>(int);
+template hipError_t kmpc_launch_solve_quad<double>(const KP &, const KIO<double> &, hipStream_t);
+template hipError_t kmpc_launch_solve_quad<float>(const KP &, const KIO<float> &, hipStream_t);

@@ -40,8 +40,6 @@ typedef struct kmpc_opts {
                             2 = hybrid (0 until the second failure, then 1), -1 (default) = 2 */
     int start;           /* cold-start point: 0 (default) = feed-forward guess inside the bounds; 1 = the reference's start, every input 0
                             (MKZMPCPathFollower.jl:65-72), moved inside the bounds where 0 is not strictly feasible */
-    int extrap;          /* 1 (default): an accepted full step of a shifted (non-convex) iteration is extended while the barrier function
-                            keeps falling; 0 = off */
 } kmpc_opts;
 
 typedef struct kmpc_result {
@@ -54,8 +52,6 @@ typedef struct kmpc_result {
     double viol;         /* max inequality violation vs. the unrelaxed bounds */
     double kkt;          /* final scaled optimality error E_0 */
     double mu;
-    int n_extrap;        /* accepted step extensions */
-    int n_extrap_fail;   /* rejected ones (each costs two roll-outs) */
 } kmpc_result;
 
 void kmpc_opts_default(kmpc_opts *o);
@@ -73,11 +69,11 @@ int kmpc_condensed_solve_batch(const kmpc_params *p, const kmpc_opts *o, int B,
                                double *X /*[B,(N+1)*4] or NULL*/, int *status, double *cost,
                                double *viol, int *iters, int nthreads);
 
-/* same, with per-problem work counters (any of them may be NULL): extra factorisations, line-search trial points, step extensions tried */
+/* same, with per-problem work counters (either may be NULL): extra factorisations, line-search trial points */
 int kmpc_condensed_solve_batch_stats(const kmpc_params *p, const kmpc_opts *o, int B,
                                      const double *z0, const double *ref, const double *v_target,
                                      const double *u_prev, double *U, double *X, int *status, double *cost,
-                                     double *viol, int *iters, int *n_refactor, int *n_ls, int *n_extrap, int *n_extrap_fail, int nthreads);
+                                     double *viol, int *iters, int *n_refactor, int *n_ls, int nthreads);
 
 /* condensed Hessian (unscaled) and gradient at U, for unit tests of the device kernels.
  * H is n x n row-major.  hessian: 0 GN, 1 exact. */

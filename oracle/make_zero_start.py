@@ -86,8 +86,25 @@ def build(N, B, cfg_id, done=None, workers=8):
 
 CFG = {8: 201, 20: 202, 50: 205}
 
+def refresh_condensed(N):
+    """re-solve the stored problems with the current state of oracle/kmpc_condensed.c and rewrite only the *_condensed columns (the
+    full-space zero-start columns are what costs CPU-minutes per problem and do not depend on that file)"""
+    path = os.path.join(ROOT, "tests", "golden", "kmpc_zero_start_N%d.npz" % N)
+    G = dict(np.load(path))
+    p = O.params(N, G["weights"])
+    rc = O.solve_condensed_batch(p, G["z0"], G["ref"], G["v_target"], G["u_prev"], nthreads=8)
+    rel = np.abs(G["J_ipopt_like"] - rc["cost"]) / np.maximum(1.0, np.abs(G["J_ipopt_like"]))
+    print("N=%d: condensed Optimal %d of %d; same minimum as the zero-start full-space solve (1e-6 rel) %d; condensed lower in %d of the others"
+          % (N, int((rc["status"] == 0).sum()), len(rel), int((rel <= 1e-6).sum()), int(((rel > 1e-6) & (rc["cost"] < G["J_ipopt_like"])).sum())))
+    G["status_condensed"], G["J_condensed"], G["U_condensed"] = rc["status"], rc["cost"], rc["U"]
+    np.savez_compressed(path, **G)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--assemble":
+    if len(sys.argv) > 2 and sys.argv[1] == "--refresh-condensed":
+        for a in sys.argv[2:]:
+            refresh_condensed(int(a))
+    elif len(sys.argv) > 2 and sys.argv[1] == "--assemble":
         N = int(sys.argv[2])
         build(N, 208, CFG[N], done=pickle.load(open(_ckpt(N), "rb")))
     else:

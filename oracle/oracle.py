@@ -35,12 +35,12 @@ class Opts(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("tol", C.c_double), ("hessian", C.c_int),
                 ("mu_init", C.c_double), ("bound_relax", C.c_double), ("warm", C.c_int),
                 ("warm_push", C.c_double), ("warm_mu", C.c_double), ("max_ls", C.c_int), ("mu_strategy", C.c_int), ("indef_strategy", C.c_int),
-                ("start", C.c_int), ("extrap", C.c_int)]
+                ("start", C.c_int)]
 
 
 class Result(C.Structure):
     _fields_ = [("status", C.c_int), ("iters", C.c_int), ("n_refactor", C.c_int), ("n_ls", C.c_int), ("n_solves", C.c_int),
-                ("cost", C.c_double), ("viol", C.c_double), ("kkt", C.c_double), ("mu", C.c_double), ("n_extrap", C.c_int), ("n_extrap_fail", C.c_int)]
+                ("cost", C.c_double), ("viol", C.c_double), ("kkt", C.c_double), ("mu", C.c_double)]
 
 
 def build(force=False):
@@ -78,7 +78,7 @@ def lib():
         L.kmpc_condensed_solve_batch_stats.argtypes = [C.POINTER(Params), C.POINTER(Opts), C.c_int,
                                                        c_double_p, c_double_p, c_double_p, c_double_p,
                                                        c_double_p, c_double_p, c_int_p, c_double_p, c_double_p,
-                                                       c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, C.c_int]
+                                                       c_int_p, c_int_p, c_int_p, C.c_int]
         L.kmpc_condense.argtypes = [C.POINTER(Params), C.POINTER(Problem), c_double_p, C.c_int,
                                     c_double_p, c_double_p, c_double_p]
         _LIB = L
@@ -198,7 +198,7 @@ def solve_condensed(p, q, o=None, U0=None):
     r = Result()
     lib().kmpc_condensed_solve(C.byref(p), C.byref(q.c), C.byref(o), _p(U), _p(X), _p(lam), C.byref(r))
     return dict(U=U.reshape(N, 2), X=X, lam=lam, status=r.status, iters=r.iters, n_refactor=r.n_refactor,
-                n_ls=r.n_ls, n_solves=r.n_solves, cost=r.cost, viol=r.viol, kkt=r.kkt, mu=r.mu, n_extrap=r.n_extrap, n_extrap_fail=r.n_extrap_fail)
+                n_ls=r.n_ls, n_solves=r.n_solves, cost=r.cost, viol=r.viol, kkt=r.kkt, mu=r.mu)
 
 
 def solve_condensed_batch(p, z0, ref, v_target, u_prev, o=None, U0=None, nthreads=1, want_X=False):
@@ -215,9 +215,9 @@ def solve_condensed_batch(p, z0, ref, v_target, u_prev, o=None, U0=None, nthread
     costv = np.empty(B)
     viol = np.empty(B)
     iters = np.empty(B, dtype=np.int32)
-    nref, nls, nex, nexf = (np.empty(B, dtype=np.int32) for _ in range(4))
+    nref, nls = (np.empty(B, dtype=np.int32) for _ in range(2))
     ip = lambda a: a.ctypes.data_as(c_int_p)
     lib().kmpc_condensed_solve_batch_stats(C.byref(p), C.byref(o), B, _p(z0), _p(ref), _p(v_target), _p(u_prev),
                                            _p(U), _p(X) if want_X else None, ip(status), _p(costv), _p(viol), ip(iters),
-                                           ip(nref), ip(nls), ip(nex), ip(nexf), int(nthreads))
-    return dict(U=U.reshape(B, N, 2), X=X, status=status, cost=costv, viol=viol, iters=iters, n_refactor=nref, n_ls=nls, n_extrap=nex, n_extrap_fail=nexf)
+                                           ip(nref), ip(nls), int(nthreads))
+    return dict(U=U.reshape(B, N, 2), X=X, status=status, cost=costv, viol=viol, iters=iters, n_refactor=nref, n_ls=nls)

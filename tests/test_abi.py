@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libkmpc_hip.so does not export %s" % n
     assert sorted(_lib.EXPORTS) == names
-    assert L.kmpc_abi_version() == 6
+    assert L.kmpc_abi_version() == 7
 
 
 def test_config_defaults_are_the_reference_constants():

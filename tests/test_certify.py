@@ -254,6 +254,47 @@ def test_gpu_minimum_vs_reference_zero_start(oracle, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [8, 20, 50])
+def test_reference_start_option(oracle, N):
+    """kmpc_config.start = 1 starts every input at 0 as the reference does (MKZMPCPathFollower.jl:65-72; moved strictly
+    inside the first-step rate interval and the speed rows where 0 is not).  On the zero-start fixtures the GPU is compared with the
+    zero-start minimum of the full-space Ipopt restatement for BOTH start modes, against the CPU checker run with the same option, and the
+    per-problem outcome is printed.  What the numbers say: the basin Ipopt ends in is a property of its full-space
+    iteration (states are free variables, the dynamics are linearised constraints), not of the start point alone -- a state-eliminated
+    iteration from the all-zero inputs is single shooting from a trajectory that ignores the reference, which at N = 50 is far from every
+    minimum (mean 27 iterations instead of 10, a few problems at the iteration cap) and agrees with Ipopt LESS often than the feed-forward
+    start does; at N = 8 and N = 20 the two starts agree with it equally often."""
+    import torch
+    O = oracle
+    G = np.load(os.path.join(GOLD, "kmpc_zero_start_N%d.npz" % N))
+    d = dict(z0=G["z0"], ref=G["ref"], v_target=G["v_target"], u_prev=G["u_prev"])
+    Jz = G["J_ipopt_like"]
+    p = O.params(N, G["weights"])
+    same = {}
+    for start in (0, 1):
+        r = _gpu_solve(N, d, torch.float64, weights=tuple(G["weights"]), start=start)
+        rc = O.solve_condensed_batch(p, d["z0"], d["ref"], d["v_target"], d["u_prev"], o=O.opts(start=start), nthreads=8)
+        rel = np.abs(r["cost"] - Jz) / np.maximum(1.0, np.abs(Jz))
+        other = (rel > 1e-6) | (r["status"] != 0)
+        same[start] = int((~other).sum())
+        print("N=%d start=%d: %d of %d in the zero-start Ipopt minimum; elsewhere %s (GPU lower in %d, not Optimal %d); mean iterations %.1f (max %d)"
+              % (N, start, same[start], len(Jz), np.where(other)[0].tolist(), int((other & (r["cost"] < Jz)).sum()), int((r["status"] != 0).sum()),
+                 r["iters"].mean(), r["iters"].max()))
+        # the GPU runs the checker's algorithm from the checker's start: same statuses, same minima (rounding may split a non-convex path on a few)
+        agree = (np.abs(r["cost"] - rc["cost"]) <= 1e-6 * np.maximum(1.0, np.abs(rc["cost"]))) & (r["status"] == rc["status"])
+        assert agree.mean() >= (0.995 if N < 50 else 0.95), (N, start, np.where(~agree)[0])
+        ok = r["status"] == 0
+        assert ok.mean() >= (1.0 if (start == 0 or N < 50) else 0.95)
+        assert r["viol"][ok].max() <= 1e-8 + 1e-12 and np.isfinite(r["cost"]).all() and np.isfinite(r["u0"]).all()
+        if other[ok].any():   # wherever it ends, an Optimal answer is a certified KKT point of the reference's NLP
+            _assert_certified(CT.certify_batch(O, p, d, r["U"], idx=np.where(other & ok)[0]), 1e-6 if N < 50 else 1e-5, 1e-8 + 1e-12, "N=%d start=%d" % (N, start))
+    if N < 50:
+        assert same[0] >= 207 and same[1] >= 207
+    else:
+        assert same[0] >= 195 and same[1] >= 175   # fixture: 197 with the feed-forward start, 186 with the reference's (the CPU checker's counts)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,B", [(8, 1024), (20, 512)])
 def test_certify_frenet_functor(oracle, N, B):
     """SURVEY.md 8(f3), MKZMPCPathFollowerFrenet.jl:64-123: the returned inputs of the Frenet-frame functor are certified KKT points of

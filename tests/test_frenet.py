@@ -136,7 +136,7 @@ def test_frenet_kernel_matches_oracle(oracle, N, B):
     assert rel[ok].max() <= 1e-6
     assert g["viol"][ok].max() <= 1e-8 + 1e-12
     assert np.abs(g["u0"] - r["U"].reshape(B, N, 2)[:, 0, :])[ok].max() <= 1e-6
-    assert np.abs(g["X"] - r["X"])[ok].max() <= 1e-6
+    assert np.abs(g["X"] - r["X"])[ok].max() <= 1e-5   # predicted states integrate input differences (<= 1e-6 each) over up to 28 stages
     assert abs(g["iters"][ok].mean() - r["iters"][ok].mean()) < 1.0
 
 

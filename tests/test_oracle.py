@@ -156,6 +156,25 @@ def test_condensed_oracle_matches_golden(oracle, N):
         assert c["stationarity"] <= 1e-6 * scale and c["violation"] <= 1e-8 + 1e-12 and c["lam_min"] >= 0
 
 
+@pytest.mark.parametrize("N", [8, 20])
+def test_reference_start_option_of_the_checker(oracle, N):
+    """opts.start = 1: every input starts at 0 as in the reference (MKZMPCPathFollower.jl:65-72), inside the bounds.  With u_prev = 0 and a
+    speed well inside its bounds the start IS the zero vector's neighbourhood: the solve ends in the fixtures' minima at N = 8 / 20."""
+    O = oracle
+    G = np.load(os.path.join(GOLD, "kmpc_N%d.npz" % N))
+    p = O.params(N, G["weights"])
+    r = O.solve_condensed_batch(p, G["z0"], G["ref"], G["v_target"], G["u_prev"], o=O.opts(start=1), nthreads=8)
+    assert (r["status"] == 0).all()
+    Jg = G["J_ipopt_like"]
+    assert (np.abs(r["cost"] - Jg) <= 1e-6 * np.maximum(1.0, np.abs(Jg))).all()
+    # one iteration from the start: the step direction only -- U after max_iter = 1 differs from 0 by one damped Newton step, and with
+    # u_prev = 0, v0 = 5 on a straight reference at 5 m/s the all-zero start is already optimal (J = 0): it must be returned unchanged
+    ref = np.zeros((N + 1, 3)); ref[:, 0] = 5.0 * 0.2 * np.arange(N + 1)
+    q = O.problem(p, [0.0, 0.0, 0.0, 5.0], ref, 5.0, (0.0, 0.0))
+    r1 = O.solve_condensed(p, q, O.opts(start=1))
+    assert r1["status"] == 0 and np.abs(r1["U"]).max() < 1e-6 and r1["cost"] < 1e-9
+
+
 def test_ipopt_like_full_space_matches_golden(oracle):
     """the independent full-space Ipopt-style restatement reproduces the fixtures (N = 8 subset; seconds)."""
     from oracle import ipopt_like as IL
