@@ -47,8 +47,8 @@ def algorithmic_flops_per_iteration(N):
 def executed_flops_per_iteration(N):
     # what the kernels execute since round 2: condensing by the O(N^2) adjoint recursion -- per stage and live column 5 FMAs to recover G_s,
     # 4 for the two Hessian rows, 2 for the second-order row, 5 for A^T p, 10 for W G (52 flops), columns 0..2s+1 live at stage s -- plus the
-    # suffix scans of the terminal sensitivities (~40 N); linearisation and the IPM step as in SURVEY.md 8(d).  The SURVEY formula (above)
-    # stays the numerator of `roofline.frac` so that rounds compare; this one says how much arithmetic is actually issued.
+    # suffix scans of the terminal sensitivities (~40 N); linearisation and the IPM step as in SURVEY.md 8(d).  This is the numerator of
+    # `roofline.achieved` / `frac` (round 3); the SURVEY formula (above) is kept beside it as `frac_survey_model` so that rounds compare.
     n, m = 2 * N, 10 * N - 4
     return 150 * N + 52 * N * (N + 1) + 40 * N + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
 
@@ -155,7 +155,7 @@ def other_config(N, B, dtype, cfg_id, dev, local, steps=5, warmup=2):
     tf_model = algorithmic_flops_per_iteration(N) * iters * B / (ms * 1e-3) / 1e12
     es = 8 if dtype == "f64" else 4
     r = {"workload": "batch=%d, N=%d, %s, 1 GPU, seeded synthetic (cfg_id %d)" % (B, N, dtype, cfg_id), "solves_per_s": B / (ms * 1e-3),
-         "kernel": kernel_name(N, dtype), "kernel_ms": ms, "launches": steps, "mean_iterations": iters, "max_iterations": int(out["iters"].max().item()),
+         "kernel": kernel_name(N, dtype, B), "kernel_ms": ms, "launches": steps, "mean_iterations": iters, "max_iterations": int(out["iters"].max().item()),
          "optimal_fraction": float((out["status"] == 0).float().mean().item()),
          "achieved_tflops": tf, "peak_tflops": peak, "frac_of_peak": tf / peak, "frac_survey_model": tf_model / peak,
          "flops_note": "frac_of_peak prices the flops the kernel executes (O(N^2) adjoint condensing); frac_survey_model the SURVEY 8(d) formula",
@@ -261,6 +261,8 @@ def parity_sample(N, d, out, ro, tol=1e-6):
 def kernel_name(N, dtype, B=4096):
     """the kernel kmpc_solve_batch dispatches (csrc/kmpc_api.hip: solve_dev; kmpc_fast_available / kmpc_wide_available / launch_fast_n)"""
     t = "double" if dtype == "f64" else "float"
+    if N == 8 and B >= 1024:               # KMPC_QUAD_MIN_BATCH: four problems per wave at the reference's own horizon (kmpc_quad.hip)
+        return "kmpc_solve_quad_kernel<%s>" % t
     if N in (8, 12, 16, 20, 24, 28):       # kmpc_fast_available: compile-time horizons with 2N + 1 <= 64
         if N <= 12 and B > 2048:
             return "kmpc_solve_fast_dense_kernel<%s,%d>" % (t, N)
@@ -571,6 +573,8 @@ def main():
                 res["config5_N50_B4096"] = other_config(50, 4096, "f64", 5, dev, local, steps=5, warmup=2)
                 # the shard one GPU of configs[3] (2 097 152 problems over 8 GPUs) gets, fp64
                 res["config4_shard_fp64_B262144"] = other_config(20, 262144, "f64", 4, dev, local, steps=3, warmup=1)
+                # the reference's own horizon (N = 8, configs[0]'s model) at the large batch: four problems per wave (kmpc_quad.hip)
+                res["N8_fp64_B262144"] = other_config(8, 262144, "f64", 3, dev, local, steps=3, warmup=1)
             # the reference's own Julia/Ipopt path is timed only if it is already installed (never fetched)
             import shutil
             res["reference_julia_ipopt_baseline"] = ("julia found at %s: not run (the reference's files do not travel)" % shutil.which("julia")) if shutil.which("julia") else "unavailable (no julia on this host)"

@@ -26,6 +26,15 @@ template <typename T> DEV T row_max(T x) {   // maximum over the row (any sign; 
     return x;
 }
 
+// value of lane J of the own 16-lane row, through the LDS crossbar only (ds_swizzle, bit-mask mode: lane' = (lane & 0x10) | J inside each
+// group of 32): no LDS memory, no address register, no write -> fence -> read round trip
+template <int J> DEV float row_bcast(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (J << 5) | 0x10)); }
+template <int J> DEV double row_bcast(double x)
+{
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), (J << 5) | 0x10), hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), (J << 5) | 0x10);
+    return __hiloint2double(hi, lo);
+}
+
 template <typename T> struct QuadSolver {
     static constexpr int N = 8;
     KMPC_HORIZON_CONSTANTS(8)
@@ -120,6 +129,7 @@ template <typename T> struct QuadSolver {
     DEV bool kkt_factor(T sc, T reg, bool want_hmax)
     {
         ipm::condense_adjoint(*this, sc);   // column j (rows >= j) of sc*H into the row's packed image
+        STAMP(3);
         if (want_hmax) cs[C_HMAX] = row_max(fabs(Lc[offc_rt(lane) + lane]));   // max |sc * H_jj|: scale of the delta_w shift
         T *dgs = cub, *sbs = clb;   // the corrector buffers are dead between the accepted step and the end of the factorisation
         ipm::kkt_diag_staging(*this, sc, reg, true, dgs, sbs);
@@ -129,17 +139,17 @@ template <typename T> struct QuadSolver {
         const T spd = (i & 1) ? (T)0 : dt2 * cb[i >> 1];   // speed rows: dt^2 * S[max(i,k)/2] on the (even, even) entries; max = i in the lower triangle
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            T v = (T)0;
-            if (k <= i) {
-                v = Lc[offc(k) + i];
-                if (!(k & 1)) v += spd;
-                if (k == i) v += dgs[k];
-                if (k == i - 2) v += sbs[k];
-            }
-            a[k] = v;
+            // (branch-free: a lane above the diagonal reads the column's diagonal entry and discards it)
+            const bool low = k <= i;
+            T v = Lc[offc(k) + (low ? i : k)];
+            if (!(k & 1)) v += spd;
+            v += k == i ? dgs[k] : (T)0;
+            if (k < 14) v += k == i - 2 ? sbs[k] : (T)0;
+            a[k] = low ? v : (T)0;
         }
         T b = -sc * gb[i];
         WFENCE();   // image, dgs / sbs consumed: the exchange buffer and (later) the image may be overwritten
+        STAMP(4);
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -160,42 +170,38 @@ template <typename T> struct QuadSolver {
             WFENCE();
         }
         yv = b;
+        STAMP(12);
         // L goes to the row's packed image (sc*H there is dead; a refactorisation re-condenses): the substitutions read the lane's row
         // (forward) and column (backward) of it from there instead of holding 32 more registers across the whole iteration
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (k <= i) Lc[offc(k) + i] = a[k];
+        for (int k = 0; k < 16; ++k) Lc[k <= i ? offc(k) + i : O_EX - O_LC + i] = a[k];   // (entries above the diagonal go to a scratch slot of the exchange buffer)
         WFENCE();
         return ok;   // (not positive definite: NaNs may have been produced above; nothing is used in that case)
     }
-    DEV T back_subst(T z) const   // L^T x = z
+    template <int I> DEV void back_step(T &z) const
     {
-        T *xe = ex;
-#pragma unroll
-        for (int i = 15; i >= 0; --i) {
-            const T xi_c = z * rd;
-            if (lane == i) xe[i] = xi_c;
-            WFENCE();
-            const T xi = xe[i];
-            const T lij = lane < i ? Lc[offc_rt(lane) + i] : (T)0;   // L[i][lane]: column `lane` of L; lanes > i hold finished components
-            z = lane == i ? xi : fma(-lij, xi, z);
-        }
-        WFENCE();
+        const T xi = row_bcast<I>(z * rd);                          // x_I, finished in lane I
+        const T lij = Lc[offc_rt(lane) + (lane < I ? I : lane)];    // L[I][lane]: column `lane` of L (lanes >= I read their diagonal and discard it)
+        z = lane == I ? xi : (lane < I ? fma(-lij, xi, z) : z);
+        __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from hoisting all 16 column loads to the top (32 more live registers)
+    }
+    DEV T back_subst(T z) const   // L^T x = z: 16 dependent steps, each one row-local broadcast
+    {
+        back_step<15>(z); back_step<14>(z); back_step<13>(z); back_step<12>(z); back_step<11>(z); back_step<10>(z); back_step<9>(z); back_step<8>(z);
+        back_step<7>(z); back_step<6>(z); back_step<5>(z); back_step<4>(z); back_step<3>(z); back_step<2>(z); back_step<1>(z); back_step<0>(z);
         return z;
+    }
+    template <int J> DEV void fwd_step(T &b) const
+    {
+        const T wj = row_bcast<J>(b * rd);                          // w_J, finished in lane J
+        const T lij = Lc[offc(J) + (lane > J ? lane : J)];          // L[lane][J]: row `lane` of L
+        b = lane == J ? wj : (lane > J ? fma(-lij, wj, b) : b);
+        __builtin_amdgcn_sched_barrier(0);
     }
     DEV T fwd_subst(T b) const    // L w = b
     {
-        T *xe = ex + 16;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const T wj_c = b * rd;
-            if (lane == j) xe[j] = wj_c;
-            WFENCE();
-            const T wj = xe[j];
-            const T lij = lane > j ? Lc[offc(j) + lane] : (T)0;       // L[lane][j]: row `lane` of L
-            b = lane == j ? wj : fma(-lij, wj, b);
-        }
-        WFENCE();
+        fwd_step<0>(b); fwd_step<1>(b); fwd_step<2>(b); fwd_step<3>(b); fwd_step<4>(b); fwd_step<5>(b); fwd_step<6>(b); fwd_step<7>(b);
+        fwd_step<8>(b); fwd_step<9>(b); fwd_step<10>(b); fwd_step<11>(b); fwd_step<12>(b); fwd_step<13>(b); fwd_step<14>(b); fwd_step<15>(b);
         return b;
     }
     DEV T kkt_affine() { return back_subst(yv); }                           // K^-1 (-sc g)

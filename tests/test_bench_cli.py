@@ -37,11 +37,12 @@ def test_bench_line_single_gpu():
     assert ms["seeds"] >= 8 and ms["min"] <= ms["mean"] <= ms["max"] and ms["all_optimal"] and ms["optimal_fraction"] == 1.0 and len(ms["per_seed"]) == ms["seeds"]
     tb = d["two_batches_in_flight"]
     assert tb["batches_in_flight"] == 2 and tb["all_optimal"] and tb["solves_per_s"] > d["value"]   # the next batch fills the tail
-    for key, kern_peak in (("config3_fp32_B262144", 157.3), ("config5_N50_B4096", 78.6), ("config4_shard_fp64_B262144", 78.6)):
+    for key, kern_peak in (("config3_fp32_B262144", 157.3), ("config5_N50_B4096", 78.6), ("config4_shard_fp64_B262144", 78.6), ("N8_fp64_B262144", 78.6)):
         c = d[key]
         assert c["optimal_fraction"] == 1.0 and c["peak_tflops"] == kern_peak and 0 < c["frac_of_peak"] < c["frac_survey_model"] < 1 and c["solves_per_s"] > 0
     assert d["config3_fp32_B262144"]["kernel"] == "kmpc_solve_fast_kernel<float,20>" and d["config5_N50_B4096"]["kernel"] == "kmpc_solve_wide_kernel<double,50>"
     assert d["config5_N50_B4096"]["solves_per_s"] >= 4e5
+    assert d["N8_fp64_B262144"]["kernel"] == "kmpc_solve_quad_kernel<double>" and d["N8_fp64_B262144"]["solves_per_s"] >= 4e7
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     c1 = d["cpu_baseline_config1"]   # BASELINE.md section 3, run C1: CPU port, 1 thread, the module-load problem cold + its 10 Hz continuation
