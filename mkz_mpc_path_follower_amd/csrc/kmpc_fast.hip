@@ -125,8 +125,9 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
     DEV void refresh_ids() { asm volatile("" : "+v"(lane)); vid = lane; }
     DEV T &cu(int i) { return cub[lane + 64 * i]; }   // corrector terms live in LDS
     DEV T &cl(int i) { return clb[lane + 64 * i]; }
-    DEV void save_best(T U) { ubest[lane] = U; }
-    DEV T load_best() const { return ubest[lane]; }
+    DEV void save_best1(T U) { ubest[lane] = U; }
+    DEV T load_best1() const { return ubest[lane]; }
+    KMPC_IPM_ONE_SLOT_HOOKS
     template <int NS, int NM> DEV void reduce(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM])   // sums and NON-NEGATIVE maxima, wave-uniform results
     {
 #pragma unroll
@@ -142,18 +143,16 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
     DEV T sum_stages(T x) const { return dpp_sum(x); }
     DEV T stage_bcast(T x, int k) const { return readlane_(x, k); }
     DEV T max_any(T x) const { return dpp_max(x); }
-    DEV void forms_apply(T x, T (&y)[NF]) { ipm::forms_apply(*this, x, y); }
-    DEV void stage_form_weights(const T (&w)[NF]) { ipm::stage_form_weights(*this, w); }
+    DEV void forms_apply(T x, T (&y)[NF]) { ipm::forms_apply(*this, x, y); }   // (scalar forms for the Frenet functor's own code)
     DEV T forms_applyT(const T (&w)[NF]) { return ipm::forms_applyT(*this, w); }
-    DEV bool interior_point(T &Uf) { return ipm::interior_point(*this, Uf); }
     // roll-out + objective at U (lane j: U_j)
-    DEV T eval(T U, StageF<T> &S)
+    DEV T eval1(T U, StageF<T> &S)
     {
         if constexpr (MODEL == 1) return eval_frenet(U, S);
         else return ipm::eval_cartesian(*this, U, S);
     }
     // costates -> gradient (returned, lane j: g_j, and left in gb); per-stage scalars go to the LDS records
-    DEV T linearize(const StageF<T> &S, bool exact)
+    DEV T linearize1(const StageF<T> &S, bool exact)
     {
         if constexpr (MODEL == 1) { const T g = linearize_frenet(S, exact); gb[lane] = g; return g; }
         else return ipm::linearize_cartesian(*this, S, exact);
@@ -602,8 +601,8 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
         return factor(kt);
     }
     // S^-1 L~^-1 (-sc*g) sits in row n of the factor image; re-read where needed rather than held in registers
-    DEV T kkt_affine() { return back_subst(lane < n ? Lc[offc_rt(lane) + n] : (T)0); }                                        // K^-1 (-sc g)
-    DEV T kkt_direction(T b) { return back_subst((lane < n ? Lc[offc_rt(lane) + n] : (T)0) + diag_solve(fwd_subst(b))); }    // K^-1 (-sc g + b)
+    DEV T kkt_affine1() { return back_subst(lane < n ? Lc[offc_rt(lane) + n] : (T)0); }                                        // K^-1 (-sc g)
+    DEV T kkt_direction1(T b) { return back_subst((lane < n ? Lc[offc_rt(lane) + n] : (T)0) + diag_solve(fwd_subst(b))); }    // K^-1 (-sc g + b)
 
     DEV void solve(const KIO<T> &io, int b) { ipm::solve(*this, io, b); }
 };
@@ -623,7 +622,7 @@ template <typename T, int N> DEV void kmpc_solve_fast_body(const KP &P, const KI
     ipm::run_solver<FastSolver<T, N>>(P, io, smem);
 }
 template <typename T, int N>
-__global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N >= 28 ? 1 : 2) : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_kernel(KP P, KIO<T> io)
 {
     kmpc_solve_fast_body<T, N>(P, io);
 }
@@ -710,7 +709,7 @@ static hipError_t launch_fast_n(const KP &P, const KIO<T> &io, hipStream_t st)
 // Frenet-frame functor (kmpc_config.model = 1): io.ref carries k_poly [B,4]  (fp64 at N = 28: 34.5 KB of LDS per wave leave one wave per
 // SIMD anyway, so the bound says so and the allocator may use all 512 registers)
 template <typename T, int N>
-__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N >= 28 ? 1 : (N <= 8 ? 3 : 2)) : (N <= 20 ? 4 : 3)) void kmpc_solve_fast_frenet_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N >= 28 ? 1 : (N <= 8 ? 3 : 2)) : (N <= 20 ? 4 : (N >= 28 ? 2 : 3))) void kmpc_solve_fast_frenet_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N, 1>::lds_elems() * sizeof(T)];
     ipm::run_solver<FastSolver<T, N, 1>>(P, io, smem);

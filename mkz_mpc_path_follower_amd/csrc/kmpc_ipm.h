@@ -18,10 +18,14 @@
 //   exchanges          reduce<NS,NM>(sums, non-negative maxima), reduce_flag<NS,NM>(.., all-true flag), max_any(x), rec_writer(),
 //                      sum_stages(x) (sum over the lanes of a stage vector), stage_bcast(x, k) (value of stage lane k)
 //   corrector terms    cu(i), cl(i)   (references: LDS in the one-wave kernel, registers in the four-wave kernel)
-//   model hooks        eval(U, S), linearize(S, exact) [leaves the gradient in gb], drop_second_order()
+//   model hooks        eval(U[NV], S), linearize(S, exact, g[NV]) [the gradient also stays with the back-end: grad(i)], drop_second_order(),
+//                      interior_point(Uf[NV]), forms_apply(x[NV], y[NF]), forms_applyT(w[NF], o[NV]), stage_form_weights(w[NF]),
+//                      form_bounds(f, bu, bl), form_relax(f, upper), dim_N() / dim_n() / dim_nf(), stage_t
 //   KKT hooks          kkt_factor(sc, reg, want_hmax) [condense + assemble + factor; max |sc H_jj| -> cs[C_HMAX] when asked],
-//                      kkt_affine() = K^-1 (-sc g),  kkt_direction(b) = K^-1 (-sc g + b)
-//   best iterate       save_best(U), load_best()
+//                      kkt_affine(x[NV]) = K^-1 (-sc g),  kkt_direction(b[NV], x[NV]) = K^-1 (-sc g + b)
+//   best iterate       save_best(U[NV]), load_best(U[NV])
+// NV = input slots per thread: 1 in the compile-time-horizon back-ends (their model code below is written for one element per thread),
+// up to 2 in the generic kernel (kmpc_kernels.hip, run-time horizon, its own model and KKT code), which instantiates only ipm::solve.
 #pragma once
 #include "kmpc_math.h"
 
@@ -50,6 +54,29 @@ enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J,
     /* start of column j minus j, so that element (row i, col j) lives at offc(j) + i */                                         \
     static constexpr int offc(int j) { return j * (n + 1) - j * (j - 1) / 2 - j; }                                               \
     static DEV int offc_rt(int j) { return j * (n + 1) - ((j * (j - 1)) >> 1) - j; }
+
+// The array-shaped hooks ipm::solve calls, for back-ends with ONE input slot per thread (NV = 1: every compile-time-horizon back-end), on top
+// of their scalar model / KKT members eval1, linearize1 (gradient left in gb), kkt_affine1, kkt_direction1, save_best1, load_best1.
+#define KMPC_IPM_ONE_SLOT_HOOKS                                                                                        \
+    static constexpr int NV = 1;                                                                                        \
+    typedef StageV<T> stage_t;                                                                                          \
+    static constexpr int dim_N() { return N_; }                                                                         \
+    static constexpr int dim_n() { return n; }                                                                          \
+    static constexpr int dim_nf() { return nf; }                                                                        \
+    DEV void form_bounds(int f, T &bu, T &bl) const { ipm::form_bounds(*this, f, bu, bl); }                             \
+    DEV T form_relax(int f, bool upper) const { return ipm::form_relax(*this, f, upper); }                              \
+    DEV void forms_apply(const T (&x)[1], T (&y)[NF]) { ipm::forms_apply(*this, x[0], y); }                             \
+    DEV void forms_applyT(const T (&w)[NF], T (&o)[1]) { o[0] = ipm::forms_applyT(*this, w); }                          \
+    DEV void stage_form_weights(const T (&w)[NF]) { ipm::stage_form_weights(*this, w); }                                \
+    DEV bool interior_point(T (&Uf)[1]) { return ipm::interior_point(*this, Uf[0]); }                                   \
+    DEV T eval(const T (&U)[1], stage_t &S) { return eval1(U[0], S); }                                                  \
+    DEV void linearize(const stage_t &S, bool exact, T (&g)[1]) { g[0] = linearize1(S, exact); }                        \
+    DEV T grad(int) const { return gb[vid]; }                                                                           \
+    DEV void kkt_affine(T (&x)[1]) { x[0] = kkt_affine1(); }                                                            \
+    DEV void kkt_direction(const T (&b)[1], T (&x)[1]) { x[0] = kkt_direction1(b[0]); }                                 \
+    DEV void save_best(const T (&U)[1]) { save_best1(U[0]); }                                                           \
+    DEV void load_best(T (&U)[1]) { U[0] = load_best1(); }
+
 
 namespace ipm {
 
@@ -504,9 +531,11 @@ template <class SV> DEV typename SV::real debug_linearize_at(SV &sv, const KP &P
 {
     typedef typename SV::real T;
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
-    const T U = sv.vid < SV::n ? io.U[(size_t)b * SV::n + sv.vid] : (T)0;
+    const T U[1] = {sv.vid < SV::n ? io.U[(size_t)b * SV::n + sv.vid] : (T)0};
     sv.eval(U, St);
-    return sv.linearize(St, P.hessian == 1);
+    T g[1];
+    sv.linearize(St, P.hessian == 1, g);
+    return g[0];
 }
 
 // ---- the solve -------------------------------------------------------------------------------------------------------------------------
@@ -519,14 +548,17 @@ template <class SV> DEV typename SV::real debug_linearize_at(SV &sv, const KP &P
 template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int b)
 {
     typedef typename SV::real T;
-    constexpr int N = SV::N_, n = SV::n, nf = SV::nf, NF = SV::NF, NTH = SV::NTH;
+    constexpr int NF = SV::NF, NV = SV::NV, NTH = SV::NTH;   // form / input slots per thread (slot i of a thread is index vid + NTH * i), threads per problem
+    const int N = s.dim_N(), n = s.dim_n(), nf = s.dim_nf();   // compile-time constants in the compile-time-horizon back-ends, run-time values in the generic one
     const KP &P = s.P;
     const T kappa_eps = 10, kappa_mu = (T)0.2, tau_min = (T)0.99, kappa_sigma = (T)1e10, eta_phi = (T)1e-8, s_max = 100;
     // the integer options are copied out of the kernel arguments once (the argument tuple is not touched inside the loop)
     const int max_ls = P.max_ls, max_iter = P.max_iter, indef_cfg = P.indef_strategy;
     const bool warm = P.warm != 0;
     const bool exact = P.hessian == 1;
-    T U, Ut, du = 0;
+    T U[NV], Ut[NV], du[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) du[i] = (T)0;
     // slacks are iterates, advanced by s -/+ alpha * a_f^T du (as in Ipopt): recomputing b - a_f^T U would lose 7 digits to
     // cancellation once an active slack is ~1e-9
     T sup[NF], slo[NF], isu[NF], isl[NF], lu[NF], ll[NF], aut[NF], w[NF];  // isu/isl = 1/slack, refreshed when the slacks move
@@ -539,7 +571,7 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
     cs[C_AD] = 0; cs[C_J] = 0; cs[C_LGS] = 0; cs[C_JP] = (T)1e30;
     int indef = indef_cfg == 2 ? 0 : indef_cfg, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
     bool have_best = false;
-    T mu = s.pt[warm ? PT_WARM_MU : PT_MU_INIT], sc = 1, Jt = 0, alpha = 0, reg = 0;
+    T mu = warm ? s.pt[PT_WARM_MU] : s.pt[PT_MU_INIT], sc = 1, Jt = 0, alpha = 0, reg = 0;
     bool use_exact = exact;
     enum { FIRST = 0, TRIAL = 1, REFACTOR = 2, FINAL = 3, RESTEP = 4 };
     const bool pc = P.mu_strategy == 1;
@@ -549,35 +581,46 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
 #pragma unroll
     for (int i = 0; i < NF; ++i) s.cu(i) = s.cl(i) = (T)0;
     int mode = FIRST;
-    StageV<T> St;
+    typename SV::stage_t St;
     STAMP_DECL_AT(s)
 
     {
-        T Uf;
+        T Uf[NV];
         const bool feas = s.interior_point(Uf);
         if (!feas) {
             status = 2;
-            const T ub = s.pt[(s.vid & 1) ? PT_STEER_MAX : PT_A_MAX];
-            U = s.vid < n ? fmin(fmax(s.up(s.vid & 1), -ub), ub) : (T)0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int j = s.vid + NTH * i;
+                const T ub = (j & 1) ? s.pt[PT_STEER_MAX] : s.pt[PT_A_MAX];   // (constant table indices: the generic back-end keeps the table in registers)
+                U[i] = j < n ? fmin(fmax(s.up(j & 1), -ub), ub) : (T)0;
+            }
             mode = FINAL;
         } else if (warm && io.warmU) {
-            const T dw = s.vid < n ? io.warmU[(size_t)b * n + s.vid] - Uf : (T)0;
-            forms_apply(s, Uf, w);
-            forms_apply(s, dw, aut);
+            T dw[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { const int j = s.vid + NTH * i; dw[i] = j < n ? io.warmU[(size_t)b * n + j] - Uf[i] : (T)0; }
+            s.forms_apply(Uf, w);
+            s.forms_apply(dw, aut);
             T th = 1;
 #pragma unroll
             for (int i = 0; i < NF; ++i)
                 if (fv[i]) {
                     T bu_, bl_;
-                    form_bounds(s, s.vid + NTH * i, bu_, bl_);
+                    s.form_bounds(s.vid + NTH * i, bu_, bl_);
                     if (aut[i] > 0) th = fmin(th, (bu_ - w[i]) / aut[i]);
                     if (aut[i] < 0) th = fmin(th, (bl_ + w[i]) / -aut[i]);
                 }
             th = -s.max_any(-th) * ((T)1 - s.pt[PT_WARM_PUSH]);
-            U = Uf + th * dw;
-        } else U = Uf;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) U[i] = Uf[i] + th * dw[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) U[i] = Uf[i];
+        }
     }
-    Ut = U;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) Ut[i] = U[i];
     STAMP_AT(s, 0);
 #pragma nounroll
     for (;;) {
@@ -586,7 +629,10 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
         s.refresh_ids();
         if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && cs[C_ERR] <= s.pt[PT_TOL])) {
             // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
-            Ut = s.load_best(); U = Ut; status = 0; final_reuse = false;
+            s.load_best(Ut);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) U[i] = Ut[i];
+            status = 0; final_reuse = false;
         }
         // refactor / restep passes re-use the linearisation of U; a stop decided on the iterate that was just evaluated re-uses that too
         if (mode != REFACTOR && mode != RESTEP && !final_reuse) Jt = s.eval(Ut, St);
@@ -607,19 +653,30 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 else lgt += log_pos(pos ? a_ * b_ : (T)1, s.kc);
             }
             if (sizeof(T) == 8) lgt = log_pos(lpr, s.kc);
-            T sm[1] = {lgt}, mx[2] = {fabs(alpha * du), fabs(U)};
+            T sm[1] = {lgt}, mx[2] = {(T)0, (T)0};
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { mx[0] = fmax(mx[0], fabs(alpha * du[i])); mx[1] = fmax(mx[1], fabs(U[i])); }
             s.template reduce_flag<1, 2>(sm, mx, okp);
             const T slg = sm[0];
             const T phi = sc * Jt - mu * slg;
             const T phi0 = cs[C_PHI0];
             if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * cs[C_DPHI])) {
                 // safeguard: the corrected direction is tried at the full step only; redo the step without the corrector term
-                if (corr_active) { mode = RESTEP; Ut = U; continue; }
+                if (corr_active) {
+                    mode = RESTEP;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Ut[i] = U[i];
+                    continue;
+                }
                 if (++ls >= max_ls) {
-                    status = cs[C_ERR] <= s.pt[PT_TOL_X100] ? 0 : 3; mode = FINAL; Ut = U; continue;  // acceptable level
+                    status = cs[C_ERR] <= s.pt[PT_TOL_X100] ? 0 : 3; mode = FINAL;   // acceptable level
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Ut[i] = U[i];
+                    continue;
                 }
                 alpha *= (T)0.5;
-                Ut = U + alpha * du;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) Ut[i] = U[i] + alpha * du[i];
                 continue;
             }
             // Ipopt's tiny-step rule: two accepted steps in a row below 10 eps relative to the iterate -> the arithmetic cannot improve
@@ -627,7 +684,11 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
             {
                 const T stepn = mx[0], umax = fmax((T)1, mx[1]);
                 n_tiny = stepn <= (T)10 * Real<T>::eps() * umax ? n_tiny + 1 : 0;
-                if (n_tiny >= 2) { U = Ut; status = cs[C_ERR] <= s.pt[PT_TOL_X1000] ? 0 : 3; tiny_stop = true; mode = FINAL; final_reuse = true; continue; }
+                if (n_tiny >= 2) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) U[i] = Ut[i];
+                    status = cs[C_ERR] <= s.pt[PT_TOL_X1000] ? 0 : 3; tiny_stop = true; mode = FINAL; final_reuse = true; continue;
+                }
             }
             // accepted: dual step from the pre-step slacks, then the slacks advance with the step
             cs[C_LGS] = slg;  // = sum log(slack) of the new iterate: the next barrier value re-uses it
@@ -645,19 +706,24 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
         const bool restep = mode == RESTEP;
         if (!restep) {
             if (mode != REFACTOR) {
-                U = Ut; cs[C_J] = Jt;
-                const T g = s.linearize(St, exact && gn_hold == 0);  // = use_exact of this iteration (set below, before gn_hold counts down)
+#pragma unroll
+                for (int i = 0; i < NV; ++i) U[i] = Ut[i];
+                cs[C_J] = Jt;
+                T g[NV];
+                s.linearize(St, exact && gn_hold == 0, g);  // = use_exact of this iteration (set below, before gn_hold counts down); the gradient also stays with the back-end (grad(i))
                 STAMP_AT(s, 1);
                 if (mode == FIRST) {
-                    forms_apply(s, U, w);
+                    s.forms_apply(U, w);
 #pragma unroll
                     for (int i = 0; i < NF; ++i) {
                         T bu_, bl_;
-                        form_bounds(s, s.vid + NTH * i, bu_, bl_);
+                        s.form_bounds(s.vid + NTH * i, bu_, bl_);
                         sup[i] = bu_ - w[i]; slo[i] = bl_ + w[i];
                         isu[i] = fv[i] ? (T)1 / sup[i] : (T)0; isl[i] = fv[i] ? (T)1 / slo[i] : (T)0;
                     }
-                    T sm[1] = {(T)0}, mx[1] = {fabs(g)};
+                    T sm[1] = {(T)0}, mx[1] = {(T)0};
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) mx[0] = fmax(mx[0], fabs(g[i]));
 #pragma unroll
                     for (int i = 0; i < NF; ++i) if (fv[i]) sm[0] += log_pos(sup[i] * slo[i], s.kc);
                     s.template reduce<1, 1>(sm, mx);
@@ -673,13 +739,21 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                         ll[i] = fmax(fmin(ll[i], kappa_sigma * mu * isl[i]), mu * isl[i] * ((T)1 / kappa_sigma));
                     }
                 }
-                if (iters >= max_iter) { mode = FINAL; Ut = U; final_reuse = true; continue; }  // status stays ITERATION_LIMIT
+                if (iters >= max_iter) {   // status stays ITERATION_LIMIT
+                    mode = FINAL; final_reuse = true;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Ut[i] = U[i];
+                    continue;
+                }
                 ++iters;
                 // optimality error (Ipopt's scaled test + unscaled duality-gap bound)
 #pragma unroll
                 for (int i = 0; i < NF; ++i) w[i] = lu[i] - ll[i];
-                const T rd = sc * g + forms_applyT(s, w);
-                T sm[2] = {(T)0, (T)0}, mx[2] = {fabs(rd), (T)0};
+                T at[NV];
+                s.forms_applyT(w, at);
+                T sm[2] = {(T)0, (T)0}, mx[2] = {(T)0, (T)0};
+#pragma unroll
+                for (int i = 0; i < NV; ++i) mx[0] = fmax(mx[0], fabs(sc * g[i] + at[i]));
 #pragma unroll
                 for (int i = 0; i < NF; ++i) {
                     const T cu = sup[i] * lu[i], cl = slo[i] * ll[i];
@@ -707,7 +781,12 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 n_flat = fabs(Jt - cs[C_JP]) <= (T)20 * Real<T>::eps() * fmax((T)1, fabs(Jt)) ? n_flat + 1 : 0;
                 cs[C_JP] = Jt;
                 if (n_flat >= 12 && err0 <= s.pt[PT_TOL_X1000]) done = true;
-                if (done || n_accept >= 15) { status = 0; mode = FINAL; Ut = U; final_reuse = true; continue; }
+                if (done || n_accept >= 15) {
+                    status = 0; mode = FINAL; final_reuse = true;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Ut[i] = U[i];
+                    continue;
+                }
                 const T mu_min = fmax(s.pt[PT_TOL_D100], fmin(s.pt[PT_TOL_D10], (T)0.1 * gap_lim * sc * inv2nf));
                 cs[C_MUF] = mu_min;
 #pragma nounroll
@@ -727,10 +806,10 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 first_attempt = true;
                 STAMP_AT(s, 2);
             }
-            // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along as row n
+            // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along
 #pragma unroll
             for (int i = 0; i < NF; ++i) w[i] = lu[i] * isu[i] + ll[i] * isl[i];
-            stage_form_weights(s, w);
+            s.stage_form_weights(w);
             STAMP_AT(s, 6);
             const bool factored = s.kkt_factor(sc, reg, use_exact && indef == 1 && first_attempt);
             first_attempt = false;
@@ -739,17 +818,21 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 // Indefinite exact Hessian: strategy 0 -> Gauss-Newton for this and the next 2 iterations; 1 -> Ipopt's inertia
                 // correction K + delta_w*I, delta_w = 1e-2*max|sc*H_jj| (x10) the first time, last/3 (x3: back to the last shift that worked) afterwards;
                 // 2 -> 0 until the second failure, 1 from then on (Gauss-Newton leaves a saddle only slowly)
-                if (++attempt >= 40) { status = 3; mode = FINAL; Ut = U; final_reuse = true; continue; }
-                if (use_exact && indef == 1) {
-                    const T hmax = cs[C_HMAX], dw_last = cs[C_DWL];
-                    if (reg == (T)0) reg = dw_last > (T)0 ? fmax((T)1e-10 * hmax, dw_last / (T)3) : (T)1e-2 * hmax;
-                    else reg *= dw_last > (T)0 ? (T)KMPC_DW_GROW : (T)10;
-                    if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; s.drop_second_order(); }
-                } else if (use_exact) {
-                    use_exact = false; gn_hold = 2; s.drop_second_order();
-                    if (indef_cfg == 2 && ++n_fail >= 2) { indef = 1; gn_hold = 0; }
-                } else reg = reg == (T)0 ? (T)1e-8 : reg * (T)100;  // last resort: shift the Gauss-Newton matrix
-                mode = REFACTOR; Ut = U;
+                bool giveup = ++attempt >= 40;
+                if (!giveup) {
+                    if (use_exact && indef == 1) {
+                        const T hmax = cs[C_HMAX], dw_last = cs[C_DWL];
+                        if (reg == (T)0) reg = dw_last > (T)0 ? fmax((T)1e-10 * hmax, dw_last / (T)3) : (T)1e-2 * hmax;
+                        else reg *= dw_last > (T)0 ? (T)KMPC_DW_GROW : (T)10;
+                        if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; s.drop_second_order(); }
+                    } else if (use_exact) {
+                        use_exact = false; gn_hold = 2; s.drop_second_order();
+                        if (indef_cfg == 2 && ++n_fail >= 2) { indef = 1; gn_hold = 0; }
+                    } else reg = reg == (T)0 ? (T)1e-8 : reg * (T)100;  // last resort: shift the Gauss-Newton matrix
+                    mode = REFACTOR;
+                } else { status = 3; mode = FINAL; final_reuse = true; }
+#pragma unroll
+                for (int i = 0; i < NV; ++i) Ut[i] = U[i];
                 continue;
             }
             if (use_exact && reg > (T)0) cs[C_DWL] = reg;
@@ -759,8 +842,9 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
             corr_active = false;
             if (pc) {
                 // Mehrotra predictor: affine-scaling step on the same factor -> this iteration's barrier target
-                const T dua = s.kkt_affine();
-                forms_apply(s, dua, aut);
+                T dua[NV];
+                s.kkt_affine(dua);
+                s.forms_apply(dua, aut);
                 // step lengths to the boundary as reciprocals: 1/alpha = max(1, max_f(-ds/s)); for the affine step -dlam/lam = 1 + ds/s
                 T sm[1] = {(T)0}, mx[2] = {(T)1, (T)1};
 #pragma unroll
@@ -801,12 +885,18 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
         // centering (+ corrector) part of the step: du = K^{-1}(-sc*g - A^T((mu - corr)/s_u - (mu - corr)/s_l))
 #pragma unroll
         for (int i = 0; i < NF; ++i) w[i] = -((mu - s.cu(i)) * isu[i] - (mu - s.cl(i)) * isl[i]);
-        du = s.kkt_direction(forms_applyT(s, w));
+        {
+            T bw[NV];
+            s.forms_applyT(w, bw);
+            s.kkt_direction(bw, du);
+        }
         STAMP_AT(s, 15);
-        forms_apply(s, du, aut);
+        s.forms_apply(du, aut);
         const T tau = fmax(tau_min, (T)1 - mu);
         {
-            T sm[1] = {s.vid < n ? sc * s.gb[s.vid] * du : (T)0}, mx[2] = {(T)0, (T)0};
+            T sm[1] = {(T)0}, mx[2] = {(T)0, (T)0};
+#pragma unroll
+            for (int i = 0; i < NV; ++i) sm[0] += s.vid + NTH * i < n ? sc * s.grad(i) * du[i] : (T)0;
 #pragma unroll
             for (int i = 0; i < NF; ++i)
                 if (fv[i]) {
@@ -823,29 +913,35 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
             cs[C_AD] = tau * rcp_(fmax(tau, mx[1]));
             cs[C_PHI0] = sc * cs[C_J] - mu * cs[C_LGS];
             cs[C_DPHI] = sm[0];  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
+            TRACE8(io.stamps, 128 + (iters & 127), reg, cs[C_HMAX], cs[C_DWL], cs[C_DWS], attempt, mx[0], sm[0], mx[1]);
         }
         ls = 0;
-        Ut = U + alpha * du;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) Ut[i] = U[i] + alpha * du[i];
         mode = TRIAL;
         STAMP_AT(s, 8);
     }
     STAMP_AT(s, 10);
     // ---- outputs (St / Jt are the evaluation of the returned U) ------------------------------------
-    forms_apply(s, U, w);
+    s.forms_apply(U, w);
     T viol = -(T)1e30;
 #pragma unroll
     for (int i = 0; i < NF; ++i)
         if (fv[i]) {
             const int f = s.vid + NTH * i;
             T bu_, bl_;
-            form_bounds(s, f, bu_, bl_);
-            viol = fmax(viol, fmax(w[i] - (bu_ - form_relax(s, f, true)), -w[i] - (bl_ - form_relax(s, f, false))));
+            s.form_bounds(f, bu_, bl_);
+            viol = fmax(viol, fmax(w[i] - (bu_ - s.form_relax(f, true)), -w[i] - (bl_ - s.form_relax(f, false))));
         }
     viol = s.max_any(viol);
-    if (s.vid < n) {
-        if (io.outU) io.outU[(size_t)b * n + s.vid] = U;
-        if (io.warmU) io.warmU[(size_t)b * n + s.vid] = U;
-        if (s.vid < 2) io.u0[(size_t)b * 2 + s.vid] = U;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = s.vid + NTH * i;
+        if (j < n) {
+            if (io.outU) io.outU[(size_t)b * n + j] = U[i];
+            if (io.warmU) io.warmU[(size_t)b * n + j] = U[i];
+            if (j < 2) io.u0[(size_t)b * 2 + j] = U[i];
+        }
     }
     if (io.outX && s.vid <= N) {
         T *o = io.outX + ((size_t)b * (N + 1) + s.vid) * 4;

@@ -18,7 +18,9 @@
 //                       back-tracking on the barrier function.
 // This is the generic kernel: any horizon N <= 56 at run time, matrices in LDS; it also carries the
 // Frenet-frame model (MODEL = 1) as a second dynamics functor.  Horizons with a compile-time kernel
-// (kmpc_fast.hip) run there instead.
+// (kmpc_fast.hip, kmpc_wide.hip, kmpc_quad.hip) run there instead.  The model code (a)-(c) and the KKT code (d)
+// below are this kernel's own; the interior-point iteration (e) is ipm::solve of kmpc_ipm.h -- the ONE state
+// machine all four solve kernels instantiate (up to two input slots per lane here: NV).
 //
 // Layouts
 //   n-vector  (length n = 2N, element j = 2k + {0: acc_k, 1: d_f_k}):  lane j%64, slot j/64
@@ -26,7 +28,7 @@
 //        f in [0,n) box on u_f | [n, n+R) rate forms, R = 2(N-1) | [n+R, nf) speed prefix sums
 //   stage data: lane k <-> stage / state k (k = 0..N)
 //   H tiles: lower-triangular 16x16 tiles in MFMA C/D layout (col = lane&15, row from Real<T>)
-#include "kmpc_common.h"
+#include "kmpc_ipm.h"
 
 // per-lane stage record: lane k holds state k (k = 0..N) and input k (k < N)
 template <typename T> struct Stage {
@@ -50,16 +52,34 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
     const KP &P;
     const int lane, N, n, R, nf, ld;
     T *Km, *stg, *xb, *wb, *cb, *dinv, *pan;
+    // ---- what the shared interior-point state machine (ipm::solve, kmpc_ipm.h) reads from a back-end; this kernel instantiates ONLY the
+    // state machine -- its model code (run-time horizon, up to two inputs per lane) and its KKT code (matrix in LDS) are its own
+    typedef T real;
+    typedef Stage<T> stage_t;
+    static constexpr int NTH = 64;
+    int vid;                    // = lane
+    T *cs;                      // solve scalars and the parameter table: caller-owned register arrays here (constant indices; kept outside the object so
+    const T *pt;                // that it holds no pointer into itself), LDS in the compile-time-horizon kernels
+    Coef<T> kc;
+    T cu_[NF], cl_[NF];         // corrector terms
+    T gk[NV], ubest_[NV];       // gradient of the current linearisation, last iterate that passed Ipopt's test
+    acc_t acc[NACC];            // condensed-Hessian tiles (kept across re-factorisations unless they live in the matrix the factorisation overwrites)
+    bool need_condense, exact_now;
+    T sc_;
     // problem data
-    T x0, y0, psi0, v0, vt, up0, up1, xoff, yoff;
+    T x0, y0, psi0, v0, vt, up0, up1, xoff_, yoff_;
     T rx, ry, rp;  // reference at stage `lane`
     T kp0, kp1, kp2, kp3;  // Frenet: K(s) = kp0 s^3 + kp1 s^2 + kp2 s + kp3
     T dt, dtc, Lb, rr_;
     T Cx, Cy, Cp, Cv, Cda, Cdd, Ca, Cd;
 
-    DEV Solver(const KP &p, unsigned char *smem)
-        : P(p), lane(threadIdx.x), N(p.N), n(2 * p.N), R(2 * (p.N - 1)), nf(5 * p.N - 2), ld(NT >= 5 ? 16 * NT + 1 : 2 * p.N + 1)
+    DEV Solver(const KP &p, unsigned char *smem, T *scalars /* [16] */, T *params /* [32] */)
+        : P(p), lane(threadIdx.x), N(p.N), n(2 * p.N), R(2 * (p.N - 1)), nf(5 * p.N - 2), ld(NT >= 5 ? 16 * NT + 1 : 2 * p.N + 1), vid(threadIdx.x)
     {
+        cs = scalars; pt = params;
+        ipm::fill_param_table(params, p, nf);
+        if constexpr (sizeof(T) == 8) kc.tab = kmpc_coef; else kc.tab = nullptr;   // (fp64: the polynomial coefficients straight from constant memory; fp32: literals)
+        need_condense = true; exact_now = false; sc_ = (T)1;
         Km = reinterpret_cast<T *>(smem);
         stg = Km + (NT >= 5 ? 16 * NT : n) * ld;
         xb = stg + KMPC_STG * (N + 1);
@@ -80,7 +100,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         kp0 = kp1 = kp2 = kp3 = (T)0;
         psi0 = z0[4 * (size_t)b + 2]; v0 = z0[4 * (size_t)b + 3];
         if (MODEL == 1) {  // `ref` carries k_poly [B,4]; (s, e_y) are not translation-invariant (K depends on s)
-            xoff = yoff = (T)0; x0 = z0[4 * (size_t)b]; y0 = z0[4 * (size_t)b + 1];
+            xoff_ = yoff_ = (T)0; x0 = z0[4 * (size_t)b]; y0 = z0[4 * (size_t)b + 1];
             const T *kp = ref + 4 * (size_t)b;
             kp0 = kp[0]; kp1 = kp[1]; kp2 = kp[2]; kp3 = kp[3];
             return;
@@ -88,10 +108,10 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         // the NLP is invariant under a translation of (x, y): solve it in vehicle-centred coordinates (recorded paths live hundreds
         // of metres from their origin; positions would carry ~1e-13 m of rounding = ~1e-12 in the cost, above the Armijo
         // decrease of the last iterations); predictions are shifted back on output
-        xoff = z0[4 * (size_t)b]; yoff = z0[4 * (size_t)b + 1]; x0 = (T)0; y0 = (T)0;
+        xoff_ = z0[4 * (size_t)b]; yoff_ = z0[4 * (size_t)b + 1]; x0 = (T)0; y0 = (T)0;
         if (lane <= N) {
             const T *r = ref + ((size_t)b * (N + 1) + lane) * 3;
-            rx = r[0] - xoff; ry = r[1] - yoff; rp = r[2];
+            rx = r[0] - xoff_; ry = r[1] - yoff_; rp = r[2];
         }
     }
 
@@ -239,7 +259,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
     }
 
     // ---- (b) costates, gradient (n-vector g) and per-stage scalars for the condensing loop -------
-    DEV void linearize(const Stage<T> &S, bool exact, T (&g)[NV])
+    DEV void linearize_model(const Stage<T> &S, bool exact, T (&g)[NV])
     {
         if (MODEL == 1) { linearize_frenet(S, exact, g); return; }
         const int k = lane;
@@ -837,353 +857,105 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         return ok;
     }
 
-    // ------------------------------------------------------------------------------------------
-    DEV void solve(const KIO<T> &io, int b)
+    // ---- hooks of the shared interior-point state machine ---------------------------------------------------------------------------------
+    DEV int dim_N() const { return N; }
+    DEV int dim_n() const { return n; }
+    DEV int dim_nf() const { return nf; }
+    DEV T up(int j) const { return j ? up1 : up0; }
+    DEV T xoff() const { return xoff_; }
+    DEV T yoff() const { return yoff_; }
+    DEV void refresh_ids() {}
+    DEV T &cu(int i) { return cu_[i]; }
+    DEV T &cl(int i) { return cl_[i]; }
+    DEV void save_best(const T (&U)[NV])
     {
-        const T kappa_eps = 10, kappa_mu = (T)0.2, theta_mu = (T)1.5, tau_min = (T)0.99, kappa_sigma = (T)1e10,
-                eta_phi = (T)1e-8, s_max = 100;
-        const T tol = (T)P.tol, gap_tol = (T)P.gap_tol;
-        const bool exact = P.hessian == 1;
-        T U[NV], Uf[NV], g[NV], du[NV], rhs[NV], Ut[NV];
-        T bu[NF], bl[NF], rlx[NF], su[NF], sl[NF], lu[NF], ll[NF], au[NF], aut[NF], dlu[NF], dll[NF], w[NF];
-        bool fv[NF];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) { const int f = lane + 64 * i; fv[i] = f < nf; form_bounds(f, bu[i], bl[i], rlx[i]); }
-        int status = 1, iters = 0, n_polish = 0, n_accept = 0, gn_hold = 0, n_tiny = 0, n_flat = 0;
-        T J_prev = (T)1e30;
-        bool tiny_stop = false;
-        T dw_last = 0, dw_spec = 0, hmax = 0;
-        int indef = P.indef_strategy == 2 ? 0 : P.indef_strategy, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
-        bool have_best = false;
-        T Ubest[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) Ubest[i] = (T)0;
-        T mu = P.warm ? (T)P.warm_mu : (T)P.mu_init, sc = 1, J = 0, err0 = 0;
-        Stage<T> S;  // one stage record: trial evaluations overwrite it, the returned point is re-evaluated at the end
-        acc_t acc[NACC];
-        STAMP_DECL
-
-        const bool feas = interior_point(Uf);
-        if (!feas) {
-            status = 2;  // KMPC_INFEASIBLE: hold the previous command clipped into the box
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int j = lane + 64 * i;
-                const T ub = (j & 1) ? (T)P.steer_max : (T)P.a_max;
-                U[i] = j < n ? fmin(fmax((j & 1) ? up1 : up0, -ub), ub) : (T)0;
-            }
-            J = eval(U, S);
-        } else {
-            if (P.warm && io.warmU) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) { const int j = lane + 64 * i; du[i] = j < n ? io.warmU[(size_t)b * n + j] - Uf[i] : (T)0; }
-                forms_apply(Uf, au);
-                forms_apply(du, aut);
-                T th = 1;
-#pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        const T s_u = bu[i] - au[i], s_l = bl[i] + au[i];
-                        if (aut[i] > 0) th = fmin(th, s_u / aut[i]);
-                        if (aut[i] < 0) th = fmin(th, s_l / -aut[i]);
-                    }
-                th = wave_min(th) * ((T)1 - (T)P.warm_push);
-#pragma unroll
-                for (int i = 0; i < NV; ++i) U[i] = Uf[i] + th * du[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) U[i] = Uf[i];
-            }
-            forms_apply(U, au);
-#pragma unroll
-            for (int i = 0; i < NF; ++i) { su[i] = bu[i] - au[i]; sl[i] = bl[i] + au[i]; }
-            J = eval(U, S);
-
-            STAMP(0);
-            for (int it = 0; it < P.max_iter; ++it) {
-                linearize(S, exact, g);
-                STAMP(1);
-                if (it == 0) {
-                    T gm = 0;
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) gm = fmax(gm, fabs(g[i]));
-                    gm = wave_max(gm);
-                    sc = gm > (T)100 ? (T)100 / gm : (T)1;  // Ipopt nlp_scaling_max_gradient
-#pragma unroll
-                    for (int i = 0; i < NF; ++i) { lu[i] = fv[i] ? mu / su[i] : (T)0; ll[i] = fv[i] ? mu / sl[i] : (T)0; }
-                }
-                ++iters;
-                // dual residual and optimality error
-#pragma unroll
-                for (int i = 0; i < NV; ++i) rhs[i] = sc * g[i];
-#pragma unroll
-                for (int i = 0; i < NF; ++i) w[i] = lu[i] - ll[i];
-                forms_applyT_add(w, rhs);
-                T rdm = 0, lsum = 0, cm0 = 0, gap = 0;
-#pragma unroll
-                for (int i = 0; i < NV; ++i) rdm = fmax(rdm, fabs(rhs[i]));
-#pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        lsum += lu[i] + ll[i];
-                        gap += su[i] * lu[i] + sl[i] * ll[i];
-                        cm0 = fmax(cm0, fmax(su[i] * lu[i], sl[i] * ll[i]));
-                    }
-                rdm = wave_max(rdm); lsum = wave_sum(lsum); cm0 = wave_max(cm0); gap = wave_sum(gap);
-                const T s_d = fmax(s_max, lsum / (T)(2 * nf)) / s_max;
-                err0 = fmax(rdm, cm0) / s_d;
-                // Ipopt's scaled test + an unscaled duality-gap bound: cost within gap_tol*max(1,|J|) of optimal
-                const T gap_lim = gap_tol * fmax((T)1, fabs(J));
-                // Ipopt's test (+ gap bound, pursued for at most 1 more iteration once Ipopt's test is met), or
-                // Ipopt's "acceptable level" (error <= 100*tol for 15 iterations in a row)
-                if (err0 <= tol) {  // remember the last iterate passing Ipopt's test
-                    have_best = true;
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) Ubest[i] = U[i];
-                }
-                if (err0 <= tol) {
-                    if (gap / sc <= gap_lim || n_polish >= 1) { status = 0; break; }
-                    ++n_polish;
-                } else if (n_polish > 0 && ++n_polish > 1) { status = 0; break; }
-                n_accept = err0 <= (T)100 * tol ? n_accept + 1 : 0;
-                if (n_accept >= 15) { status = 0; break; }
-                // rounding floor: the objective has not moved by more than 20 eps |J| for 12 iterations in a row -> the arithmetic cannot
-                // improve the iterate (fp32, large costs: the dual residual never settles below 100 tol); Optimal within 1e3 tol
-                n_flat = fabs(J - J_prev) <= (T)20 * Real<T>::eps() * fmax((T)1, fabs(J)) ? n_flat + 1 : 0;
-                J_prev = J;
-                if (n_flat >= 12 && err0 <= (T)1e3 * tol) { status = 0; break; }
-                const T mu_min = fmax(tol * (T)1e-2, fmin(tol / 10, (T)0.1 * gap_lim * sc / (T)(2 * nf)));
-                for (; P.mu_strategy == 0;) {  // monotone barrier update (Ipopt default); mu_strategy 1 picks mu after the predictor
-                    T cmu = 0;
-#pragma unroll
-                    for (int i = 0; i < NF; ++i)
-                        if (fv[i]) cmu = fmax(cmu, fmax(fabs(su[i] * lu[i] - mu), fabs(sl[i] * ll[i] - mu)));
-                    cmu = wave_max(cmu);
-                    if (fmax(rdm, cmu) / s_d <= kappa_eps * mu && mu > mu_min)
-                        mu = fmax(mu_min, fmin(kappa_mu * mu, pow(mu, theta_mu)));
-                    else break;
-                }
-                STAMP(2);
-                // factor K = sc*H + A^T Sigma A
-#pragma unroll
-                for (int i = 0; i < NF; ++i) w[i] = fv[i] ? lu[i] / su[i] + ll[i] / sl[i] : (T)0;
-                bool use_exact = exact && gn_hold == 0;  // GN is held for 2 iterations after an indefinite exact Hessian
-                if (gn_hold > 0) --gn_hold;
-                // Indefinite exact Hessian: indef_strategy 0 -> Gauss-Newton for this and the next 2 iterations;
-                // 1 -> Ipopt's inertia correction, K + delta_w*I with delta_w = 1e-2*max|sc*H_jj| (x10) the first time,
-                // last/3 (x8) afterwards; the accumulators are kept, so a retry is one build_K + one factorisation.
-                // in shift mode the previous iteration's delta_w / 3 is the first trial (dropped below 1e-9 * max|H_jj|)
-                T reg = 0;
-                if (use_exact && indef == 1 && dw_spec > (T)0) { reg = dw_spec / (T)3; if (reg < (T)1e-9 * hmax) reg = 0; }
-                bool factored = false, need_condense = true;
-                for (int attempt = 0; attempt < 40; ++attempt) {
-                    if (need_condense) {
-                        condense(use_exact, acc);
-                        need_condense = false;
-                        if (indef == 1 && use_exact) {  // max |sc * H_jj| over the diagonal of the tiles
-                            T hm = 0;
-                            if constexpr (LDSACC) {
-                                WSYNC();
-                                for (int j = lane; j < n; j += 64) hm = fmax(hm, fabs(sc * Km[j * ld + j]));
-                            } else {
-#pragma unroll
-                                for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r)
-                                        if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[LDSACC ? 0 : ti * (ti + 1) / 2 + ti][r]));
-                            }
-                            hmax = wave_max(hm);
-                        }
-                    }
-                    STAMP(3);
-                    stage_form_weights(w);
-                    build_K(acc, sc, reg);
-                    STAMP(4);
-                    const bool okc = cholesky();
-                    STAMP(5);
-                    if (okc) { factored = true; if (use_exact && reg > 0) dw_last = reg; if (use_exact) dw_spec = reg; break; }
-                    if (LDSACC) need_condense = true;  // the tiles lived in the matrix the factorisation just overwrote
-                    if (use_exact && indef == 1) {
-                        if (reg == 0) reg = dw_last > 0 ? fmax((T)1e-10 * hmax, dw_last / 3) : (T)1e-2 * hmax;
-                        else reg *= dw_last > 0 ? (T)KMPC_DW_GROW : (T)10;
-                        if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; need_condense = true; }
-                    } else if (use_exact) {  // drop the second-order term
-                        use_exact = false; gn_hold = 2; need_condense = true;
-                        if (P.indef_strategy == 2 && ++n_fail >= 2) { indef = 1; gn_hold = 0; }
-                    }
-                    else reg = reg == 0 ? (T)1e-8 : reg * (T)100;  // last resort: shift the Gauss-Newton matrix
-                }
-                if (!factored) { status = 3; break; }
-                // Mehrotra predictor-corrector (mu_strategy 1): affine-scaling step on the same factor -> barrier
-                // target mu = sigma*mu_cur, sigma = (mu_aff/mu_cur)^3, and the second-order complementarity term
-                T corru[NF], corrl[NF];
-#pragma unroll
-                for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
-                if (P.mu_strategy == 1) {
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) du[i] = -sc * g[i];
-                    chol_solve(du);
-                    forms_apply(du, aut);
-                    T apa = 1, ada = 1, mucur = 0, muaff = 0;
-#pragma unroll
-                    for (int i = 0; i < NF; ++i)
-                        if (fv[i]) {
-                            const T dsu = -aut[i], dsl = aut[i];
-                            const T dlu_ = -lu[i] - lu[i] / su[i] * dsu, dll_ = -ll[i] - ll[i] / sl[i] * dsl;
-                            if (dsu < 0) apa = fmin(apa, -su[i] / dsu);
-                            if (dsl < 0) apa = fmin(apa, -sl[i] / dsl);
-                            if (dlu_ < 0) ada = fmin(ada, -lu[i] / dlu_);
-                            if (dll_ < 0) ada = fmin(ada, -ll[i] / dll_);
-                            mucur += su[i] * lu[i] + sl[i] * ll[i];
-                        }
-                    apa = wave_min(apa); ada = wave_min(ada);
-#pragma unroll
-                    for (int i = 0; i < NF; ++i)
-                        if (fv[i]) {
-                            const T dsu = -aut[i], dsl = aut[i];
-                            const T dlu_ = -lu[i] - lu[i] / su[i] * dsu, dll_ = -ll[i] - ll[i] / sl[i] * dsl;
-                            muaff += (su[i] + apa * dsu) * (lu[i] + ada * dlu_) + (sl[i] + apa * dsl) * (ll[i] + ada * dll_);
-                            corru[i] = dsu * dlu_; corrl[i] = dsl * dll_;
-                        }
-                    mucur = wave_sum(mucur) / (T)(2 * nf); muaff = wave_sum(muaff) / (T)(2 * nf);
-                    const T r3 = muaff / mucur;
-                    mu = fmax(mu_min, fmin((T)1, r3 * r3 * r3) * mucur);
-                    mu = fmax(mu, fmin(mucur, rdm / s_d * ((use_exact && reg > 0) ? (T)KMPC_IKRD_NC : (T)KMPC_IKRD)));  // no barrier target far below the dual infeasibility (kmpc_ipm.h)
-                }
-                const T tau = fmax(tau_min, (T)1 - mu);
-                T ad = 1, Jt = 0, alpha_acc = 0;
-                bool accepted = false;
-                for (int pass = 0; pass < 2 && !accepted; ++pass) {
-                    if (pass == 1) {  // safeguard: the corrected direction need not be a descent direction -> drop the corrector
-                        if (P.mu_strategy != 1) break;
-#pragma unroll
-                        for (int i = 0; i < NF; ++i) corru[i] = corrl[i] = (T)0;
-                    }
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) rhs[i] = -sc * g[i];
-#pragma unroll
-                    for (int i = 0; i < NF; ++i) w[i] = fv[i] ? -((mu - corru[i]) / su[i] - (mu - corrl[i]) / sl[i]) : (T)0;
-                    forms_applyT_add(w, rhs);
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) du[i] = rhs[i];
-                    STAMP(6);
-                    chol_solve(du);
-                    STAMP(7);
-                    forms_apply(du, aut);
-                    T ap = 1, gw = 0;
-                    ad = 1;
-#pragma unroll
-                    for (int i = 0; i < NF; ++i) {
-                        dlu[i] = dll[i] = 0;
-                        if (fv[i]) {
-                            const T dsu = -aut[i], dsl = aut[i];
-                            dlu[i] = (mu - corru[i] - lu[i] * su[i]) / su[i] - lu[i] / su[i] * dsu;
-                            dll[i] = (mu - corrl[i] - ll[i] * sl[i]) / sl[i] - ll[i] / sl[i] * dsl;
-                            gw += (mu / su[i] - mu / sl[i]) * aut[i];
-                            if (dsu < 0) ap = fmin(ap, -tau * su[i] / dsu);
-                            if (dsl < 0) ap = fmin(ap, -tau * sl[i] / dsl);
-                            if (dlu[i] < 0) ad = fmin(ad, -tau * lu[i] / dlu[i]);
-                            if (dll[i] < 0) ad = fmin(ad, -tau * ll[i] / dll[i]);
-                        }
-                    }
-                    ap = wave_min(ap); ad = wave_min(ad);
-                    T lg = 0, dphi = gw;  // d/dalpha of phi_mu: (sc*g + A^T(mu/s_u - mu/s_l))^T du
-#pragma unroll
-                    for (int i = 0; i < NF; ++i) if (fv[i]) lg += log(su[i]) + log(sl[i]);
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) dphi += sc * g[i] * du[i];
-                    const T phi0 = sc * J - mu * wave_sum(lg);
-                    dphi = wave_sum(dphi);
-                    STAMP(8);
-                    T alpha = ap;
-                    const int nls = (pass == 0 && P.mu_strategy == 1) ? 1 : P.max_ls;  // the corrected direction is tried at the full step only
-                    for (int l = 0; l < nls; ++l, alpha *= (T)0.5) {
-#pragma unroll
-                        for (int i = 0; i < NV; ++i) Ut[i] = U[i] + alpha * du[i];
-                        Jt = eval(Ut, S);
-                        T lgt = 0;
-                        bool ok = true;
-#pragma unroll
-                        for (int i = 0; i < NF; ++i)
-                            if (fv[i]) {
-                                // slacks are iterates (as in Ipopt): s -/+ alpha * a_f^T du, never b - a_f^T U (cancellation)
-                                const T a_ = su[i] - alpha * aut[i], b_ = sl[i] + alpha * aut[i];
-                                if (!(a_ > 0) || !(b_ > 0)) ok = false; else lgt += log(a_) + log(b_);
-                            }
-                        ok = __all(ok);
-                        const T phi = sc * Jt - mu * wave_sum(lgt);
-                        if (ok && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * dphi) { accepted = true; alpha_acc = alpha; break; }
-                    }
-                }
-                STAMP(9);
-                if (!accepted) { status = err0 <= (T)100 * tol ? 0 : 3; break; }  // acceptable level reached
-                {   // Ipopt's tiny-step rule (see the oracle): two accepted steps in a row below 10 eps relative to the iterate
-                    T sm = 0, um = 1;
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) { sm = fmax(sm, fabs(alpha_acc * du[i])); um = fmax(um, fabs(U[i])); }
-                    sm = wave_max(sm); um = wave_max(um);
-                    n_tiny = sm <= (T)10 * Real<T>::eps() * um ? n_tiny + 1 : 0;
-                }
-#pragma unroll
-                for (int i = 0; i < NV; ++i) U[i] = Ut[i];
-                J = Jt;
-                if (n_tiny >= 2) { status = err0 <= (T)1e3 * tol ? 0 : 3; tiny_stop = true; break; }
-#pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (fv[i]) {
-                        su[i] -= alpha_acc * aut[i]; sl[i] += alpha_acc * aut[i];
-                        lu[i] += ad * dlu[i]; ll[i] += ad * dll[i];
-                        lu[i] = fmax(fmin(lu[i], kappa_sigma * mu / su[i]), mu / (kappa_sigma * su[i]));
-                        ll[i] = fmax(fmin(ll[i], kappa_sigma * mu / sl[i]), mu / (kappa_sigma * sl[i]));
-                    }
-            }
-        }
-        STAMP(10);
-        // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
-        if (have_best && !tiny_stop && !(status == 0 && err0 <= tol)) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) U[i] = Ubest[i];
-            status = 0;
-        }
-        if (status != 2) J = eval(U, S);  // stage record of the returned point (the last trial may have been rejected)
-        // ---- outputs ----------------------------------------------------------------------------
-        forms_apply(U, au);
-        T viol = -(T)1e30;
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-            if (fv[i]) {
-                // unrelaxed bounds: b - rlx ; speed forms relax upper/lower separately
-                T ru = rlx[i], rl = rlx[i];
-                const int f = lane + 64 * i;
-                if (f >= n + R) {
-                    ru = (T)P.relax * fmax((T)1, fabs((T)P.v_max));
-                    rl = (T)P.relax * fmax((T)1, fabs((T)P.v_min));
-                }
-                viol = fmax(viol, fmax(au[i] - (bu[i] - ru), -au[i] - (bl[i] - rl)));
-            }
-        viol = wave_max(viol);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int j = lane + 64 * i;
-            if (j < n) {
-                if (io.outU) io.outU[(size_t)b * n + j] = U[i];
-                if (io.warmU) io.warmU[(size_t)b * n + j] = U[i];
-                if (j < 2) io.u0[(size_t)b * 2 + j] = U[i];
-            }
-        }
-        if (io.outX && lane <= N) {
-            T *o = io.outX + ((size_t)b * (N + 1) + lane) * 4;
-            o[0] = S.x + xoff; o[1] = S.y + yoff; o[2] = S.psi; o[3] = S.v;
-        }
-        STAMP(11);
-        STAMP_OUT(io.stamps, b);
-        if (lane == 0) {
-            io.status[b] = status;
-            if (io.cost) io.cost[b] = J;
-            if (io.viol) io.viol[b] = viol;
-            if (io.iters) io.iters[b] = iters;
-        }
+        for (int i = 0; i < NV; ++i) ubest_[i] = U[i];
     }
+    DEV void load_best(T (&U)[NV]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) U[i] = ubest_[i];
+    }
+    template <int NS, int NM> DEV void reduce(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sm[i] = wave_sum(sm[i]);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) mx[i] = wave_max(mx[i]);
+    }
+    template <int NS, int NM> DEV void reduce_flag(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM], bool &all_true) const
+    {
+        all_true = __all(all_true);
+        reduce<NS, NM>(sm, mx);
+    }
+    DEV T max_any(T x) const { return wave_max(x); }
+    DEV void form_bounds(int f, T &bu, T &bl) const { T rlx; form_bounds(f, bu, bl, rlx); }
+    DEV T form_relax(int f, bool upper) const   // the relaxation contained in form_bounds (speed forms relax upper / lower separately)
+    {
+        const T relax = (T)P.relax;
+        if (f < n) return relax * fmax((T)1, (f & 1) ? (T)P.steer_max : (T)P.a_max);
+        if (f < n + R) { const int r = f - n; return relax * fmax((T)1, ((r & 1) ? (T)P.steer_dmax : (T)P.a_dmax) * ((r >> 1) == 0 ? dtc : dt)); }
+        return relax * fmax((T)1, fabs(upper ? (T)P.v_max : (T)P.v_min));
+    }
+    DEV void forms_applyT(const T (&w)[NF], T (&o)[NV])
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) o[i] = (T)0;
+        forms_applyT_add(w, o);
+    }
+    DEV void linearize(const Stage<T> &S, bool exact, T (&g)[NV])
+    {
+        linearize_model(S, exact, g);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) gk[i] = g[i];
+        exact_now = exact; need_condense = true;
+    }
+    DEV T grad(int i) const { return gk[i]; }
+    DEV void drop_second_order() { exact_now = false; need_condense = true; }   // (the condensing takes the Gauss-Newton / exact choice as a flag)
+    // condense (kept across re-factorisations) + K = sc*(H + input Hessian) + A^T W A + reg*I in LDS + blocked Cholesky; needs stage_form_weights done
+    DEV bool kkt_factor(T sc, T reg, bool want_hmax)
+    {
+        sc_ = sc;
+        if (need_condense) {
+            condense(exact_now, acc);
+            need_condense = false;
+            if (want_hmax) {  // max |sc * H_jj|: scale of the delta_w shift
+                T hm = 0;
+                if constexpr (LDSACC) {
+                    WSYNC();
+                    for (int j = lane; j < n; j += 64) hm = fmax(hm, fabs(sc * Km[j * ld + j]));
+                } else {
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[LDSACC ? 0 : ti * (ti + 1) / 2 + ti][r]));
+                }
+                cs[C_HMAX] = wave_max(hm);
+            }
+        }
+        STAMP(3);
+        build_K(acc, sc, reg);
+        STAMP(4);
+        const bool ok = cholesky();
+        if (!ok && LDSACC) need_condense = true;  // the tiles lived in the matrix the factorisation just overwrote
+        return ok;
+    }
+    DEV void kkt_affine(T (&x)[NV])                          // K^-1 (-sc g)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) x[i] = -sc_ * gk[i];
+        chol_solve(x);
+    }
+    DEV void kkt_direction(const T (&b)[NV], T (&x)[NV])     // K^-1 (-sc g + b)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) x[i] = -sc_ * gk[i] + b[i];
+        chol_solve(x);
+    }
+
+    DEV void solve(const KIO<T> &io, int b) { ipm::solve(*this, io, b); }
 };
 
 template <typename T, int NT>
@@ -1197,7 +969,8 @@ __global__ __launch_bounds__(64) void kmpc_solve_kernel(KP P, KIO<T> io)
       for (int e = threadIdx.x; e < ne_; e += 64) w_[e] = (T)NAN;
       __syncthreads(); }
 #endif
-    Solver<T, NT> sv(P, smem);
+    T scalars[16], params[32];
+    Solver<T, NT> sv(P, smem, scalars, params);
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
     sv.solve(io, b);
 }
@@ -1213,7 +986,8 @@ __global__ __launch_bounds__(64) void kmpc_solve_frenet_kernel(KP P, KIO<T> io)
       for (int e = threadIdx.x; e < ne_; e += 64) w_[e] = (T)NAN;
       __syncthreads(); }
 #endif
-    Solver<T, NT, 1> sv(P, smem);
+    T scalars[16], params[32];
+    Solver<T, NT, 1> sv(P, smem, scalars, params);
     sv.load_problem(io.z0, io.ref, io.vt, io.up, b);  // io.ref = k_poly [B,4]
     sv.solve(io, b);
 }
@@ -1226,7 +1000,8 @@ __global__ __launch_bounds__(64) void kmpc_condense_kernel(KP P, KDbg<T> io)
     typedef Solver<T, NT> SV;
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= P.B) return;
-    SV sv(P, smem);
+    T scalars[16], params[32];
+    SV sv(P, smem, scalars, params);
     sv.load_problem(io.z0, io.ref, io.vt, nullptr, b);
     const int n = 2 * P.N;
     T U[SV::NV], g[SV::NV];
@@ -1234,7 +1009,7 @@ __global__ __launch_bounds__(64) void kmpc_condense_kernel(KP P, KDbg<T> io)
     for (int i = 0; i < SV::NV; ++i) { const int j = lane + 64 * i; U[i] = j < n ? io.U[(size_t)b * n + j] : (T)0; }
     Stage<T> S;
     const T J = sv.eval(U, S);
-    sv.linearize(S, P.hessian == 1, g);
+    sv.linearize_model(S, P.hessian == 1, g);
     typename SV::acc_t acc[SV::NACC];
     sv.condense(P.hessian == 1, acc);
     if (SV::LDSACC) WSYNC();

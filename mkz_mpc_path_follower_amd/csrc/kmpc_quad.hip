@@ -11,8 +11,10 @@
 //     results (each level adds the same two partial sums in either order), which is what keeps a row's 16 lanes on one control path.
 //   * KKT: the 16 x 16 matrix is one row (i) per lane, in registers; Cholesky is 16 right-looking column steps whose only exchange is one
 //     per-row LDS all-gather of the pivot column; the right-hand side -sc*g rides along (forward substitution inside the factorisation).
-//     The substitutions are 16 dependent steps each (forward on the lane's row of L, backward on its column, fetched once through the
-//     packed image); at this size the matrix cores have nothing to offer -- a trailing update is n^3/3 = 1.4 k flops per problem.
+//     The substitutions are FOUR dependent block steps each: every quad of lanes inverts its 4x4 diagonal block of L once per factorisation
+//     (quad-permute DPP), a block step is one quad-local product, a row-local broadcast of the four finished components (ds_swizzle) and four
+//     FMAs with entries of the lane's row / column read from the packed image; at this size the matrix cores have nothing to offer -- a
+//     trailing update is n^3/3 = 1.4 k flops per problem.
 // Results agree with the one-wave kernel to rounding (different summation trees), not bit for bit: tests/test_quad.py.
 #include "kmpc_ipm.h"
 
@@ -35,6 +37,8 @@ template <int J> DEV double row_bcast(double x)
     return __hiloint2double(hi, lo);
 }
 
+template <int R, typename T> DEV T quad_bcast(T x) { return dpp_mov0<R | (R << 2) | (R << 4) | (R << 6), 0xf>(x); }   // value of lane R of the own quad
+
 template <typename T> struct QuadSolver {
     static constexpr int N = 8;
     KMPC_HORIZON_CONSTANTS(8)
@@ -56,7 +60,8 @@ template <typename T> struct QuadSolver {
     const T *pt, *cwt;
     Coef<T> kc;
     T psi0, v0, vt, up0, up1, rx, ry, rp, xoff_, yoff_;
-    T rd;      // 1 / L[lane][lane]
+    T dinv[4]; // row (lane & 3) of D_q^-1, D_q = the 4x4 diagonal block of L this lane's row runs through (q = lane >> 2)
+    T dcol[4]; // column (lane & 3) of D_q^-1
     T yv;      // (L^-1 (-sc g))[lane]
 
     DEV QuadSolver(const KP &p, unsigned char *smem) : P(p), lane(threadIdx.x & 15), vid(threadIdx.x & 15), row(threadIdx.x >> 4)
@@ -94,8 +99,9 @@ template <typename T> struct QuadSolver {
     DEV void refresh_ids() { asm volatile("" : "+v"(lane)); vid = lane; }
     DEV T &cu(int i) { return cub[lane + 16 * i]; }
     DEV T &cl(int i) { return clb[lane + 16 * i]; }
-    DEV void save_best(T U) { ubest[lane] = U; }
-    DEV T load_best() const { return ubest[lane]; }
+    DEV void save_best1(T U) { ubest[lane] = U; }
+    DEV T load_best1() const { return ubest[lane]; }
+    KMPC_IPM_ONE_SLOT_HOOKS
     template <int NS, int NM> DEV void reduce(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM])
     {
 #pragma unroll
@@ -118,10 +124,8 @@ template <typename T> struct QuadSolver {
         WFENCE();
         return v;
     }
-    DEV void stage_form_weights(const T (&w)[NF]) { ipm::stage_form_weights(*this, w); }
-    DEV bool interior_point(T &Uf) { return ipm::interior_point(*this, Uf); }
-    DEV T eval(T U, StageV<T> &S) { return ipm::eval_cartesian(*this, U, S); }
-    DEV T linearize(const StageV<T> &S, bool exact) { return ipm::linearize_cartesian(*this, S, exact); }
+    DEV T eval1(T U, StageV<T> &S) { return ipm::eval_cartesian(*this, U, S); }
+    DEV T linearize1(const StageV<T> &S, bool exact) { return ipm::linearize_cartesian(*this, S, exact); }
     DEV void drop_second_order() { ipm::drop_second_order_cartesian(*this); }
 
     // ---- KKT: K = sc*(H + input Hessian) + A^T W A + reg*I, one row per lane, Cholesky + the affine right-hand side in one sweep ------------
@@ -151,6 +155,7 @@ template <typename T> struct QuadSolver {
         WFENCE();   // image, dgs / sbs consumed: the exchange buffer and (later) the image may be overwritten
         STAMP(4);
         bool ok = true;
+        T rd = (T)0;   // 1 / L[i][i]
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             ex[i] = a[j];        // column j of the current Schur complement (rows < j: stale values nobody reads)
@@ -175,37 +180,70 @@ template <typename T> struct QuadSolver {
         // (forward) and column (backward) of it from there instead of holding 32 more registers across the whole iteration
 #pragma unroll
         for (int k = 0; k < 16; ++k) Lc[k <= i ? offc(k) + i : O_EX - O_LC + i] = a[k];   // (entries above the diagonal go to a scratch slot of the exchange buffer)
+        // Inverses of the four 4x4 diagonal blocks of L, one per quad of lanes, for substitutions in FOUR dependent block steps instead of
+        // sixteen: lane (q, r) gathers its quad's block through quad-permute DPP, inverts it redundantly and keeps row r and column r
+        {
+            const int q = i >> 2, r = i & 3;
+            T blk[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const T v = q == 0 ? a[c] : (q == 1 ? a[4 + c] : (q == 2 ? a[8 + c] : a[12 + c]));   // L[i][4q + c]
+                blk[c] = c < r ? v : (T)0;
+            }
+            const T r0 = quad_bcast<0>(rd), r1 = quad_bcast<1>(rd), r2 = quad_bcast<2>(rd), r3 = quad_bcast<3>(rd);
+            const T D10 = quad_bcast<1>(blk[0]), D20 = quad_bcast<2>(blk[0]), D21 = quad_bcast<2>(blk[1]);
+            const T D30 = quad_bcast<3>(blk[0]), D31 = quad_bcast<3>(blk[1]), D32 = quad_bcast<3>(blk[2]);
+            const T i10 = -D10 * r0 * r1;
+            const T i21 = -D21 * r1 * r2, i20 = -fma(D21, i10, D20 * r0) * r2;
+            const T i32 = -D32 * r2 * r3, i31 = -fma(D32, i21, D31 * r1) * r3, i30 = -fma(D32, i20, fma(D31, i10, D30 * r0)) * r3;
+            // inverse (lower triangular): rows (r0, 0, 0, 0), (i10, r1, 0, 0), (i20, i21, r2, 0), (i30, i31, i32, r3)
+            dinv[0] = r == 0 ? r0 : (r == 1 ? i10 : (r == 2 ? i20 : i30));
+            dinv[1] = r == 0 ? (T)0 : (r == 1 ? r1 : (r == 2 ? i21 : i31));
+            dinv[2] = r <= 1 ? (T)0 : (r == 2 ? r2 : i32);
+            dinv[3] = r <= 2 ? (T)0 : r3;
+            dcol[0] = r == 0 ? r0 : (T)0;
+            dcol[1] = r == 0 ? i10 : (r == 1 ? r1 : (T)0);
+            dcol[2] = r == 0 ? i20 : (r == 1 ? i21 : (r == 2 ? r2 : (T)0));
+            dcol[3] = r == 0 ? i30 : (r == 1 ? i31 : (r == 2 ? i32 : r3));
+        }
         WFENCE();
         return ok;   // (not positive definite: NaNs may have been produced above; nothing is used in that case)
     }
-    template <int I> DEV void back_step(T &z) const
+    // block step Q of L^T x = z (Q = 3 .. 0): the quad solves its 4x4 block (all quads do, on whatever they hold; quad Q's is final), its four
+    // components are broadcast inside the row, and the lanes of the earlier quads subtract them with the four entries of their column
+    template <int Q> DEV void back_block(T &z) const
     {
-        const T xi = row_bcast<I>(z * rd);                          // x_I, finished in lane I
-        const T lij = Lc[offc_rt(lane) + (lane < I ? I : lane)];    // L[I][lane]: column `lane` of L (lanes >= I read their diagonal and discard it)
-        z = lane == I ? xi : (lane < I ? fma(-lij, xi, z) : z);
-        __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from hoisting all 16 column loads to the top (32 more live registers)
-    }
-    DEV T back_subst(T z) const   // L^T x = z: 16 dependent steps, each one row-local broadcast
-    {
-        back_step<15>(z); back_step<14>(z); back_step<13>(z); back_step<12>(z); back_step<11>(z); back_step<10>(z); back_step<9>(z); back_step<8>(z);
-        back_step<7>(z); back_step<6>(z); back_step<5>(z); back_step<4>(z); back_step<3>(z); back_step<2>(z); back_step<1>(z); back_step<0>(z);
-        return z;
-    }
-    template <int J> DEV void fwd_step(T &b) const
-    {
-        const T wj = row_bcast<J>(b * rd);                          // w_J, finished in lane J
-        const T lij = Lc[offc(J) + (lane > J ? lane : J)];          // L[lane][J]: row `lane` of L
-        b = lane == J ? wj : (lane > J ? fma(-lij, wj, b) : b);
+        const T z0 = quad_bcast<0>(z), z1 = quad_bcast<1>(z), z2 = quad_bcast<2>(z), z3 = quad_bcast<3>(z);
+        const T x = fma(dcol[3], z3, dcol[2] * z2) + fma(dcol[1], z1, dcol[0] * z0);     // (D^-T z)_r = sum_c inv[c][r] z_c
+        if (Q > 0) {
+            const T x0 = row_bcast<4 * Q>(x), x1 = row_bcast<4 * Q + 1>(x), x2 = row_bcast<4 * Q + 2>(x), x3 = row_bcast<4 * Q + 3>(x);
+            const bool up = lane < 4 * Q;
+            const T *col = Lc + offc_rt(lane) + (up ? 4 * Q : lane);   // L[4Q + c][lane], c = 0..3 (lanes >= 4Q: their own diagonal, discarded)
+            const T l0 = col[0], l1 = up ? col[1] : (T)0, l2 = up ? col[2] : (T)0, l3 = up ? col[3] : (T)0;
+            const T upd = fma(l3, x3, l2 * x2) + fma(l1, x1, (up ? l0 : (T)0) * x0);
+            z = (lane >> 2) == Q ? x : (up ? z - upd : z);
+        } else z = (lane >> 2) == 0 ? x : z;
         __builtin_amdgcn_sched_barrier(0);
     }
-    DEV T fwd_subst(T b) const    // L w = b
+    DEV T back_subst(T z) const { back_block<3>(z); back_block<2>(z); back_block<1>(z); back_block<0>(z); return z; }   // L^T x = z
+    template <int Q> DEV void fwd_block(T &b) const
     {
-        fwd_step<0>(b); fwd_step<1>(b); fwd_step<2>(b); fwd_step<3>(b); fwd_step<4>(b); fwd_step<5>(b); fwd_step<6>(b); fwd_step<7>(b);
-        fwd_step<8>(b); fwd_step<9>(b); fwd_step<10>(b); fwd_step<11>(b); fwd_step<12>(b); fwd_step<13>(b); fwd_step<14>(b); fwd_step<15>(b);
-        return b;
+        const T b0 = quad_bcast<0>(b), b1 = quad_bcast<1>(b), b2 = quad_bcast<2>(b), b3 = quad_bcast<3>(b);
+        const T w = fma(dinv[3], b3, dinv[2] * b2) + fma(dinv[1], b1, dinv[0] * b0);     // (D^-1 b)_r
+        if (Q < 3) {
+            const T w0 = row_bcast<4 * Q>(w), w1 = row_bcast<4 * Q + 1>(w), w2 = row_bcast<4 * Q + 2>(w), w3 = row_bcast<4 * Q + 3>(w);
+            const bool dn = lane >= 4 * Q + 4;
+            // L[lane][4Q + c]: row `lane` of L (lanes above the block read the column's diagonal entry and discard it)
+            const T l0 = Lc[offc(4 * Q) + (dn ? lane : 4 * Q)], l1 = Lc[offc(4 * Q + 1) + (dn ? lane : 4 * Q + 1)];
+            const T l2 = Lc[offc(4 * Q + 2) + (dn ? lane : 4 * Q + 2)], l3 = Lc[offc(4 * Q + 3) + (dn ? lane : 4 * Q + 3)];
+            const T upd = fma(l3, w3, l2 * w2) + fma(l1, w1, l0 * w0);
+            b = (lane >> 2) == Q ? w : (dn ? b - upd : b);
+        } else b = (lane >> 2) == 3 ? w : b;
+        __builtin_amdgcn_sched_barrier(0);
     }
-    DEV T kkt_affine() { return back_subst(yv); }                           // K^-1 (-sc g)
-    DEV T kkt_direction(T b) { return back_subst(yv + fwd_subst(b)); }      // K^-1 (-sc g + b)
+    DEV T fwd_subst(T b) const { fwd_block<0>(b); fwd_block<1>(b); fwd_block<2>(b); fwd_block<3>(b); return b; }   // L w = b
+    DEV T kkt_affine1() { return back_subst(yv); }                           // K^-1 (-sc g)
+    DEV T kkt_direction1(T b) { return back_subst(yv + fwd_subst(b)); }      // K^-1 (-sc g + b)
 
     DEV void solve(const KIO<T> &io, int b) { ipm::solve(*this, io, b); }
 };

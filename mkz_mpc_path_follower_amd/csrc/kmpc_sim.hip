@@ -15,6 +15,7 @@
 // takes a short polynomial (<= 1 ulp-level error, like libm's) and anything else the library call:
 //   atan2(y, x), x > 0, |y / x| <= 1/8 (slip angles): odd Taylor series to t^19 (next term 8^-21 / 21 < 1e-20 relative);
 //   cos(d), |d| <= 0.6 (tyre angle, actuator-lagged command within +-0.5): even series to d^18;
+//   sin / cos(psi), psi wrapped to [-pi, pi): quadrant reduction + the Taylor polynomials on |r| <= pi/4;
 //   the heading wrap only when psi + pi has left [0, 2 pi).
 __device__ __forceinline__ double sim_atan2_pos(double y, double x)   // polynomial branch only for x > 0 (a caller-written state may carry vx < 0)
 {
@@ -34,6 +35,28 @@ __device__ __forceinline__ double sim_cos_small(double d)
     p = p * z + 1.0 / 20922789888000.0; p = p * z - 1.0 / 87178291200.0; p = p * z + 1.0 / 479001600.0; p = p * z - 1.0 / 3628800.0;
     p = p * z + 1.0 / 40320.0; p = p * z - 1.0 / 720.0; p = p * z + 1.0 / 24.0; p = p * z - 0.5;
     return 1.0 + z * p;
+}
+// sin / cos of the heading, which the model keeps wrapped to [-pi, pi): Cody-Waite reduction by pi/2 in two pieces and the Taylor
+// polynomials on |r| <= pi/4 (truncation < 1e-19), <= 1-2 ulp from libm's like the other small-argument paths; anything else -> sincos()
+__device__ __forceinline__ void sim_sincos_heading(double x, double *s, double *c)
+{
+    if (!(fabs(x) <= 4.0)) { sincos(x, s, c); return; }
+    const double k = rint(x * 0.63661977236758134308);
+    double r = x - k * 1.57079632679489655800e+00;
+    r = r - k * 6.12323399573676603587e-17;
+    const double z = r * r;
+    double ps = 1.0 / 355687428096000.0;
+    ps = ps * z - 1.0 / 1307674368000.0; ps = ps * z + 1.0 / 6227020800.0; ps = ps * z - 1.0 / 39916800.0; ps = ps * z + 1.0 / 362880.0;
+    ps = ps * z - 1.0 / 5040.0; ps = ps * z + 1.0 / 120.0; ps = ps * z - 1.0 / 6.0;
+    const double sr = r + (r * z) * ps;
+    double pc = -1.0 / 6402373705728000.0;
+    pc = pc * z + 1.0 / 20922789888000.0; pc = pc * z - 1.0 / 87178291200.0; pc = pc * z + 1.0 / 479001600.0; pc = pc * z - 1.0 / 3628800.0;
+    pc = pc * z + 1.0 / 40320.0; pc = pc * z - 1.0 / 720.0; pc = pc * z + 1.0 / 24.0; pc = pc * z - 0.5;
+    const double cr = 1.0 + z * pc;
+    const int q = (int)k & 3;
+    const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
 }
 
 __global__ __launch_bounds__(256) void kmpc_sim_kernel(int B, double *__restrict__ state, const double *__restrict__ cmd, int n_updates)
@@ -57,7 +80,7 @@ __global__ __launch_bounds__(256) void kmpc_sim_kernel(int B, double *__restrict
         const double Fyf = C_alpha_f * alpha_f, Fyr = C_alpha_r * alpha_r;  // :80-81
         const double cd = sim_cos_small(df);
         double sp, cp;
-        sincos(psi, &sp, &cp);
+        sim_sincos_heading(psi, &sp, &cp);
         // :84 reads `acc - 1/m*Fyf*np.sin(self.df) + self.wz*self.vy` with m = 1840 an int: the reference is Python 2 (print statements,
         // no `from __future__ import division`), so 1/m is INTEGER division = 0 and the lateral-force drag term vanishes (:88 uses 1.0/m)
         const double vx_n = fmax(0.0, vx + deltaT * (acc + wz * vy));

@@ -116,8 +116,8 @@ template <typename T, int N> struct WideSolver {
     DEV void refresh_ids() { asm volatile("" : "+v"(tid)); lane = tid & 63; vid = tid; }
     DEV T &cu(int) { return cu_[0]; }                  // corrector terms live in registers (one form per thread)
     DEV T &cl(int) { return cl_[0]; }
-    DEV void save_best(T U) { if (tid < 128) ubl[tid] = U; }
-    DEV T load_best() const { return ubl[tid & 127]; }  // (threads >= 128 pick up copies: their U is never read as an input -- every use is guarded by tid < n)
+    DEV void save_best1(T U) { if (tid < 128) ubl[tid] = U; }
+    DEV T load_best1() const { return ubl[tid & 127]; }  // (threads >= 128 pick up copies: their U is never read as an input -- every use is guarded by tid < n)
     template <int NS, int NM> DEV void reduce(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM]) { wg_reduce<NS, NM>(sm, mx); }
     template <int NS, int NM> DEV void reduce_flag(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM], bool &all_true)
     {
@@ -133,11 +133,10 @@ template <typename T, int N> struct WideSolver {
     DEV T sum_stages(T x) const { return dpp_sum(x); }
     DEV T stage_bcast(T x, int k) const { return readlane_(x, k); }
     DEV T max_any(T x) { T dm[1] = {(T)0}, m[1] = {x}; wg_reduce<0, 1>(dm, m); return m[0]; }
-    DEV T forms_apply(T x) { T y[1]; ipm::forms_apply(*this, x, y); return y[0]; }
-    DEV void stage_form_weights(T w) { const T w1[1] = {w}; ipm::stage_form_weights(*this, w1); }
-    DEV bool interior_point(T &Uf) { return ipm::interior_point(*this, Uf); }
-    DEV T eval(T U, StageW<T> &S) { return ipm::eval_cartesian(*this, U, S); }
-    DEV T linearize(const StageW<T> &S, bool exact) { return ipm::linearize_cartesian(*this, S, exact); }
+    DEV void stage_form_weights(T w) { const T w1[1] = {w}; ipm::stage_form_weights(*this, w1); }   // (scalar form for the diagnostics kernel)
+    DEV T eval1(T U, StageW<T> &S) { return ipm::eval_cartesian(*this, U, S); }
+    DEV T linearize1(const StageW<T> &S, bool exact) { return ipm::linearize_cartesian(*this, S, exact); }
+    KMPC_IPM_ONE_SLOT_HOOKS
     DEV void drop_second_order() { ipm::drop_second_order_cartesian(*this); }
     DEV void condense_adjoint(T sc) { ipm::condense_adjoint(*this, sc); }
 
@@ -395,8 +394,8 @@ template <typename T, int N> struct WideSolver {
         cs[C_HMAX] = hmax;
         return factored;
     }
-    DEV T kkt_affine() { return solve_dir((T)0, false); }      // K^-1 (-sc g)
-    DEV T kkt_direction(T b) { return solve_dir(b, true); }    // K^-1 (-sc g + b)
+    DEV T kkt_affine1() { return solve_dir((T)0, false); }      // K^-1 (-sc g)
+    DEV T kkt_direction1(T b) { return solve_dir(b, true); }    // K^-1 (-sc g + b)
 
     DEV void solve(const KIO<T> &io, int b) { ipm::solve(*this, io, b); }
 };

@@ -448,7 +448,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
     const double gap_tol = 1e-7;
     const int max_polish = 1;
     int gn_hold = 0;
-    double dw_last = 0.0, dw_spec = 0.0, hmax_prev = 0.0;
+    double dw_last = 0.0, dw_spec = 0.0, hmax_prev = 0.0, reg_final = 0.0;
     /* Tuned on the pooled worst-of-4096 statistics of 48 seeded batches (the kernels carry the same values):
        after a failed first trial (= last/3) the shift grows x3 -- back to the one that worked last iteration -- instead of x8;
        in shifted (non-convex) iterations the barrier floor is rd/100 instead of rd/1000.  Experiment overrides: KMPC_X_GROW, KMPC_X_KRDNC. */
@@ -589,7 +589,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
             for (int f = 0; f < nf; ++f) w[f] = lu[f] / su[f] + ll[f] / sl[f];
             forms_gram_add(&F, w, K);
             for (int j = 0; j < n; ++j) K[j * n + j] += reg;
-            if (chol(K, n) == 0) { if (!use_gn && reg > 0.0) dw_last = reg; if (!use_gn) dw_spec = reg; break; }
+            if (chol(K, n) == 0) { if (!use_gn && reg > 0.0) dw_last = reg; if (!use_gn) dw_spec = reg; reg_final = use_gn ? 0.0 : reg / fmax(hmax, 1e-300); break; }
             ++n_refac;
             if (!use_gn && indef_strategy == 1) {
                 if (reg == 0.0) reg = dw_last > 0.0 ? fmax(1e-10 * hmax, dw_last / 3.0) : 1e-2 * hmax;
@@ -742,7 +742,7 @@ finish:
         res->cost = kmpc_cost(p, q, U, Xl);
         res->viol = kmpc_max_violation(p, q, U);
         res->kkt = err0;
-        res->mu = mu;
+        res->mu = getenv("KMPC_X_REGFINAL") ? reg_final : mu;
     }
     free(mem);
     free(ref_local);

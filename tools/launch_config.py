@@ -8,11 +8,11 @@ from mkz_mpc_path_follower_amd import BatchMPC
 from mkz_mpc_path_follower_amd.synthetic import make_batch
 ap = argparse.ArgumentParser()
 ap.add_argument("--horizon", type=int, default=20); ap.add_argument("--dtype", default="f64"); ap.add_argument("--batch", type=int, default=4096)
-ap.add_argument("--cfg", type=int, default=2); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--seed", type=int, default=None)
+ap.add_argument("--schedule", type=int, default=1); ap.add_argument("--cfg", type=int, default=2); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--seed", type=int, default=None)
 a = ap.parse_args()
 tdt = torch.float64 if a.dtype == "f64" else torch.float32
 d = make_batch(a.batch, a.horizon, cfg_id=a.cfg, seed=a.seed)
-s = BatchMPC(N=a.horizon, dtype=tdt)
+s = BatchMPC(N=a.horizon, dtype=tdt, schedule=a.schedule)
 dev = {k: torch.as_tensor(d[k], dtype=tdt, device="cuda") for k in ("z0", "ref", "v_target", "u_prev")}
 o = None
 ev = []

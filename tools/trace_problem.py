@@ -5,7 +5,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mkz_mpc_path_follower_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "mkz_mpc_path_follower_amd", "libkmpc_hip_trace.so")
+_lib.LIB_PATH = os.path.join(ROOT, "mkz_mpc_path_follower_amd", os.environ.get("KMPC_TRACE_LIB", "libkmpc_hip_trace.so"))
 from mkz_mpc_path_follower_amd import BatchMPC
 from mkz_mpc_path_follower_amd.synthetic import make_batch
 b = int(sys.argv[1]); f32 = (sys.argv[2] if len(sys.argv) > 2 else "f64") == "f32"
@@ -24,3 +24,7 @@ print(" it        err0         rd       comp         mu               J      alp
 for k in range(1, min(it, 255) + 1):
     r = t[k]
     print("%3d  %10.3e %10.3e %10.3e %10.3e %15.8f %10.3e %3d %3d" % (k, r[0], r[1], r[2], r[3], r[4], r[5], int(r[6]), int(r[7])))
+print(" it         reg       hmax        dwl        dws  attempt   max-ds/s       dphi  max-dl/l")
+for k in range(1, min(it, 127) + 1):
+    r = t[128 + k]
+    print("%3d  %10.3e %10.3e %10.3e %10.3e %3d %10.3e %10.3e %10.3e" % (k, r[0], r[1], r[2], r[3], int(r[4]), r[5], r[6], r[7]))
