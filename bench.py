@@ -49,8 +49,11 @@ def executed_flops_per_iteration(N):
     # 4 for the two Hessian rows, 2 for the second-order row, 5 for A^T p, 10 for W G (52 flops), columns 0..2s+1 live at stage s -- plus the
     # suffix scans of the terminal sensitivities (~40 N); linearisation and the IPM step as in SURVEY.md 8(d).  This is the numerator of
     # `roofline.achieved` / `frac` (round 3); the SURVEY formula (above) is kept beside it as `frac_survey_model` so that rounds compare.
+    # Round 3: the recursion runs as two halves at the same time (stages >= M in the column's own lane, stages < M of the columns < 2M in
+    # spare lanes; same 52 flops per live column and stage) and is stitched by one rank-4 product: 8 flops per entry of the 2M x 2M lower triangle.
     n, m = 2 * N, 10 * N - 4
-    return 150 * N + 52 * N * (N + 1) + 40 * N + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
+    M = min(N // 2, (64 - n) // 2) if N <= 28 else N // 2   # kmpc_fast.hip / kmpc_wide.hip: MSPLIT
+    return 150 * N + 52 * N * (N + 1) + 40 * N + 8 * M * (2 * M + 1) + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
 
 
 def counter_profile(kernel):

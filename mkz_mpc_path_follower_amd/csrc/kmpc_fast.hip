@@ -51,13 +51,18 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
     typedef typename Real<T>::acc_t acc_t;
     typedef T real;
     static constexpr int N_ = N, NTH = 64, GS = 64, MODEL_ID = MODEL;   // what kmpc_ipm.h reads: horizon, threads per problem, stride of the G_N table, functor
+    // Split adjoint recursion (kmpc_ipm.h, condense_adjoint): lanes n .. n + 2M - 1 run the stages below M for the columns < 2M while lanes
+    // 0 .. n - 1 run the stages from M up -- M = N / 2 where 3N lanes exist (N <= 20: both halves N / 2 trips), else what the spare lanes allow
+    static constexpr int MSPLIT = MODEL == 1 ? 0 : ((64 - n) / 2 < N / 2 ? (64 - n) / 2 : N / 2), LOW0 = n, GMS = 2 * MSPLIT;
+    static constexpr int TM = (2 * MSPLIT + 15) / 16;   // 16 x 16 tiles per side that the rank-4 correction touches
+    static_assert(3 * GMS <= 64 && n + 6 * MSPLIT <= 64 * NF, "G_M lives in the spare row of opb, p(M) and the diagonal shares behind the staging rows of cub / clb");
     static constexpr int lds_elems() { return ((LC + 1) & ~1) + 64 + 64 * NF + 64 + LSTR * (N + 1) + 8 * 64 + 16 + 64 + 64 + 2 * 64 * NF + 16 * (n / 4) + (sizeof(T) == 8 ? KC_COUNT : 0); }
 
     STAMP_MEMBERS
     const KP &P;
     int lane, vid;  // stage index / input-form slot (the same lane here); re-materialised (opaque) at the top of every iteration: stops
                     // LICM from hoisting the lane-derived index / mask arithmetic of every phase out of the loop into long-lived VGPRs
-    T *Lc, *xb, *wb, *cb, *lin, *opb, *gnb, *cs, *ubest, *gb, *cub, *clb, *sinvb;
+    T *Lc, *xb, *wb, *cb, *lin, *opb, *gnb, *gmb, *hm, *cs, *ubest, *gb, *cub, *clb, *sinvb;
     Coef<T> kc;  // polynomial coefficients (LDS table in fp64)
     T x0, y0, psi0, v0, vt, up0, up1, rx, ry, rp, xoff_, yoff_;
     T kp0, kp1, kp2, kp3;  // Frenet: K(s) = kp0 s^3 + kp1 s^2 + kp2 s + kp3
@@ -73,10 +78,12 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
         lin = cb + 64;
         opb = lin + LSTR * (N + 1);
         gnb = opb + 4 * 64;     // terminal sensitivities G_N [3][64] (Cartesian model): the Cholesky panel scratch uses opb[0 .. 4 * 64) only
+        gmb = opb + 7 * 64;     // mid-horizon sensitivities G_M [3][2M] of the split recursion
         cs = opb + 8 * 64;      // wave-uniform scalars that are read once or twice per iteration live here, not in VGPRs
         ubest = cs + 16;        // last iterate that passed Ipopt's test
         gb = ubest + 64;        // gradient of the current linearisation (lane j: g_j)
         cub = gb + 64; clb = cub + 64 * NF;  // corrector terms
+        hm = cub + n + 4 * MSPLIT;  // (split recursion) p_j(M): rows 0, 1 behind the n staging entries of cub, rows 2, 3 behind those of clb; then the diagonal shares
         sinvb = clb + 64 * NF;  // D_j^-1 of the factor's 4x4 diagonal blocks (row-major, 16 per 4-column panel)
         for (int e = lane; e < 16 * (n / 4); e += 64) sinvb[e] = (T)0;
         kc.tab = sinvb + 16 * (n / 4);
@@ -123,6 +130,7 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
     DEV T yoff() const { return yoff_; }
     DEV bool rec_writer() const { return true; }
     DEV void refresh_ids() { asm volatile("" : "+v"(lane)); vid = lane; }
+    DEV T *pm(int c) const { return (c < 2 ? cub : clb) + n + (c & 1) * 2 * MSPLIT; }   // component c of p_j(M), j < 2M (the corrector buffers are dead while K is built)
     DEV T &cu(int i) { return cub[lane + 64 * i]; }   // corrector terms live in LDS
     DEV T &cl(int i) { return clb[lane + 64 * i]; }
     DEV void save_best1(T U) { ubest[lane] = U; }
@@ -406,6 +414,19 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
         const int c = lane & 15;
         const T dt2 = pt[PT_DT2];
         T *dgs = cub, *sbs = clb;  // the corrector buffers are dead between the accepted step and the end of the factorisation
+        // split recursion: rows and columns < 2M of the image lack G_M^T P_M -- a rank-4 product, one matrix-core instruction per tile, issued
+        // first so that the matrix pipe's latency passes behind the staging exchange
+        constexpr int NCM = TM * (TM + 1) / 2;
+        acc_t cmt[NCM < 1 ? 1 : NCM];
+        if constexpr (ADJ && MSPLIT > 0) {
+            T fa[TM], fb[TM];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) { fa[t] = ipm::split_fragment_a(*this, t, c, lane >> 4); fb[t] = ipm::split_fragment_b(*this, t, c, lane >> 4); }
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj) cmt[ti * (ti + 1) / 2 + tj] = Real<T>::mfma(fa[ti], fb[tj], acc_t{0, 0, 0, 0});
+        }
         ipm::kkt_diag_staging(*this, sc, reg, ADJ, dgs, sbs);
 #pragma unroll
         for (int tj = 0; tj < NTF; ++tj) {
@@ -415,7 +436,9 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
             const T dgv = dgs[cs_], sbv = sbs[cs_], rhv = -sc * gb[cs_];
             const T *colK = Lc + offc_rt(cs_);
 #pragma unroll
-            for (int ti = tj; ti < NTF; ++ti)
+            for (int ti = tj; ti < NTF; ++ti) {
+                acc_t cm = acc_t{0, 0, 0, 0};
+                if constexpr (ADJ && MSPLIT > 0) { if (ti < TM) cm = cmt[ti < TM ? ti * (ti + 1) / 2 + tj : 0]; }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + Real<T>::row_of(lane, r);
@@ -433,6 +456,7 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
                         const T *src = rd ? colK + row : pt;  // pt[0] is finite: the product with the zero mask below is exact
                         const T odm = rd ? (T)1 : (T)0;
                         v = fma(odm, *src, v);
+                        if (ADJ && MSPLIT > 0 && ti < TM) v += cm[r];
                         if (ti == tj) v += row == col ? dgv : (T)0;
                         if (ti <= tj + 1) v += row == col + 2 ? sbv : (T)0;
                     }
@@ -440,6 +464,7 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
                     if (tj == NTF - 1) v = colok ? v : (T)0;
                     kt[ti * (ti + 1) / 2 + tj][r] = v;
                 }
+            }
             // one tile column at a time: keeps the scheduler from stretching every tile's live range over the whole build
 #pragma unroll
             for (int ti = tj; ti < NTF; ++ti) asm volatile("" : "+v"(kt[ti * (ti + 1) / 2 + tj]));
@@ -585,7 +610,11 @@ template <typename T, int N, int MODEL = 0> struct FastSolver {
         acc_t (&acc)[NTT] = reinterpret_cast<acc_t (&)[NTT]>(kt);
         condense(sc, acc);
         if (ADJ) {
-            if (want_hmax) cs[C_HMAX] = dpp_max_nn(lane < n ? fabs(Lc[offc_rt(lane) + lane]) : (T)0);
+            if (want_hmax) {
+                T dj = lane < n ? Lc[offc_rt(lane) + lane] : (T)0;
+                if constexpr (MSPLIT > 0) dj += lane < 2 * MSPLIT ? hm[lane] : (T)0;   // the diagonal's share of G_M^T P_M
+                cs[C_HMAX] = dpp_max_nn(fabs(dj));
+            }
         } else if (want_hmax) {  // max |sc * H_jj| over the diagonal of the tiles
             T hm = 0;
 #pragma unroll

@@ -280,12 +280,30 @@ template <class SV> DEV typename SV::real linearize_cartesian(SV &s, const Stage
         mdd = px1 * (-dt * v * (c * b1 * b1 + sn * b2)) + py1 * (dt * v * (-sn * b1 * b1 + c * b2)) +
               pp1 * (dtL * v * (-S.sinb * b1 * b1 + S.cosb * b2));
     }
+    // Mid-horizon sensitivities for the split recursion of condense_adjoint: column j of G_M = Phi(M, k+1) B_k e_j, k < M -- the same sums
+    // truncated at stage M, i.e. the full suffix sums minus their values at lane M - 1 (the psi perturbation a stage sees does not
+    // depend on where the horizon ends):  d x_M / d v = P3(k) X2m + zx(k) - zx(M-1),  X2m = X2(k) - X2(M-1);  d psi_M / d v = P3(k) - P3(M-1)
+    T X2m = 0, Y2m = 0, zxm = 0, zym = 0, P3m = 0;
+    if constexpr (SV::MSPLIT > 0) {
+        constexpr int Mm = SV::MSPLIT - 1;
+        X2m = X2 - s.stage_bcast(X2, Mm); Y2m = Y2 - s.stage_bcast(Y2, Mm);
+        zxm = zx - s.stage_bcast(zx, Mm); zym = zy - s.stage_bcast(zy, Mm);
+        P3m = P3 - s.stage_bcast(P3, Mm);
+    }
     if (s.rec_writer()) {   // (four-wave kernel: all waves hold the same values, wave 0 publishes them)
         if (st) {
             T *q = s.gnb + 2 * k;
             q[0] = dt * fma(P3, X2, zx); q[GS] = dt * fma(P3, Y2, zy); q[2 * GS] = dt * P3;   // acceleration column: B = (0, 0, 0, dt)
             q[1] = fma(X2, Bdp, Bdx); q[GS + 1] = fma(Y2, Bdp, Bdy); q[2 * GS + 1] = Bdp;      // steering column
             s.gb[2 * k] = ga; s.gb[2 * k + 1] = gd;
+        }
+        if constexpr (SV::MSPLIT > 0) {
+            if (k < SV::MSPLIT) {
+                constexpr int GM = SV::GMS;
+                T *q = s.gmb + 2 * k;
+                q[0] = dt * fma(P3, X2m, zxm); q[GM] = dt * fma(P3, Y2m, zym); q[2 * GM] = dt * P3m;
+                q[1] = fma(X2m, Bdp, Bdx); q[GM + 1] = fma(Y2m, Bdp, Bdy); q[2 * GM + 1] = Bdp;
+            }
         }
         if (k <= N) {
             T *q = s.lin + LSTR * k;   // record N is all zero
@@ -328,20 +346,36 @@ template <class SV> DEV void load_rec(const SV &s, Rec<typename SV::real> &r, in
 template <class SV> DEV void condense_adjoint(SV &s, typename SV::real sc)
 {
     typedef typename SV::real T;
-    constexpr int N = SV::N_, n = SV::n, GS = SV::GS;
-    if (s.vid < n) {
-        const int j = s.vid;
+    constexpr int N = SV::N_, n = SV::n, GS = SV::GS, M = SV::MSPLIT, TRIPS = N - M;
+    static_assert(2 * M <= N, "the upper part of the split recursion must end at stage M");
+    // Split recursion (M = SV::MSPLIT > 0): the sequential depth of the recursion is halved by running stages N-1 .. M ("upper", thread j,
+    // every column) and stages M-1 .. 0 ("lower", thread LOW0 + j, columns j < 2M) AT THE SAME TIME.  The lower part starts from column j
+    // of G_M (closed form like G_N: linearize) and from p = 0; by linearity what its rows lack is Phi(M, s+1)^T p_j(M) seen through B_s --
+    // that is G_M[:, row]^T p_j(M), a rank-4 product of two 4 x 2M tables: ONE matrix-core instruction per 16 x 16 tile, added when the KKT
+    // tiles are assembled (split_fragment_a / _b below).  The upper threads leave p_j(M) in s.pm(c) and the diagonal's share in s.hm.
+    bool lower = false;
+    if constexpr (M > 0) lower = s.vid >= SV::LOW0 && s.vid < SV::LOW0 + 2 * M;
+    if (s.vid < n || lower) {
+        int j = s.vid;
+        if constexpr (M > 0) j = lower ? s.vid - SV::LOW0 : s.vid;
         const T dtv = s.pt[PT_DT];
         const T Cx2 = s.cwt[0], Cy2 = s.cwt[1], Cp2 = s.cwt[2], Cv2 = s.cwt[3];
-        // column j of G_N: linearize left it in the table (it depends on the linearisation only, not on the barrier weights or the shift);
+        // column j of G_N (G_M): linearize left it in the table (it depends on the linearisation only, not on the barrier weights or the shift);
         // everything downstream is linear in G, so the scaling of the objective goes in here, once
-        T gx = sc * s.gnb[j], gy = sc * s.gnb[GS + j], gp = sc * s.gnb[2 * GS + j], gv = (j & 1) ? (T)0 : sc * dtv;
-        T px = Cx2 * gx, py = Cy2 * gy, pp = Cp2 * gp, pv = (T)0;   // p(N) = W_N G_N: no second-order part and no speed cost on the terminal state
+        const T *g0 = s.gnb;
+        int gstr = GS;
+        T wl = (T)1;
+        if constexpr (M > 0) { g0 = lower ? s.gmb : s.gnb; gstr = lower ? SV::GMS : GS; wl = lower ? (T)0 : (T)1; }
+        T gx = sc * g0[j], gy = sc * g0[gstr + j], gp = sc * g0[2 * gstr + j], gv = (j & 1) ? (T)0 : sc * dtv;
+        T px = wl * Cx2 * gx, py = wl * Cy2 * gy, pp = wl * Cp2 * gp, pv = (T)0;   // p(N) = W_N G_N: no second-order part and no speed cost on the terminal state; lower part: 0
         T *colK = s.Lc + SV::offc_rt(j);
+        int st0 = N - 1;
+        if constexpr (M > 0) st0 = lower ? M - 1 : N - 1;
         Rec<T> cur;
-        load_rec(s, cur, N - 1);
+        load_rec(s, cur, st0);
 #pragma unroll 2
-        for (int st = N - 1; st >= 0; --st) {
+        for (int t = 0; t < TRIPS; ++t) {
+            const int st = st0 - t;   // (lower threads of an uneven split run out of stages first: nothing is stored for st < 0)
             Rec<T> nxt;
             load_rec(s, nxt, st > 0 ? st - 1 : 0);
             const T ra = dtv * pv;
@@ -361,8 +395,33 @@ template <class SV> DEV void condense_adjoint(SV &s, typename SV::real sc)
             pv = fma(cur.mpv, gp, fma(Cv2, gv, pv));
             cur = nxt;
         }
+        if constexpr (M > 0) {
+            if (!lower && j < 2 * M) {   // p_j(M), and what the diagonal entry (j, j) lacks (max |sc H_jj| is taken before the tiles exist)
+                s.pm(0)[j] = px; s.pm(1)[j] = py; s.pm(2)[j] = pp; s.pm(3)[j] = pv;
+                s.hm[j] = fma(s.gmb[j], px, fma(s.gmb[SV::GMS + j], py, fma(s.gmb[2 * SV::GMS + j], pp, ((j & 1) ? (T)0 : dtv) * pv)));
+            }
+        }
     }
     xsync<SV::NTH>();
+}
+// MFMA fragments of the rank-4 product G_M^T P_M for 16-row / 16-column block t (lane: c = lane & 15 index inside the block, kk = lane >> 4
+// component), zero beyond 2M.  The fourth component of G_M is dt in the acceleration columns and 0 in the steering columns.
+template <class SV> DEV typename SV::real split_fragment_a(const SV &s, int t, int c, int kk)
+{
+    typedef typename SV::real T;
+    const int i = 16 * t + c;
+    const bool ok = i < 2 * SV::MSPLIT;
+    const T g = s.gmb[SV::GMS * (kk < 3 ? kk : 0) + (ok ? i : 0)];
+    const T v = kk == 3 ? ((i & 1) ? (T)0 : s.pt[PT_DT]) : g;
+    return ok ? v : (T)0;
+}
+template <class SV> DEV typename SV::real split_fragment_b(const SV &s, int t, int c, int kk)
+{
+    typedef typename SV::real T;
+    const int i = 16 * t + c;
+    const bool ok = i < 2 * SV::MSPLIT;
+    const T v = s.pm(kk)[ok ? i : 0];
+    return ok ? v : (T)0;
 }
 
 // Strictly feasible start.  P.start = 0: a first guess of the solution inside the bounds (same rule as the CPU checker): accelerations

@@ -44,7 +44,7 @@ template <typename T> struct QuadSolver {
     KMPC_HORIZON_CONSTANTS(8)
     typedef T real;
     // what kmpc_ipm.h reads: horizon, threads per problem, forms per thread, stride of the G_N table, record stride, functor
-    static constexpr int N_ = 8, NTH = 16, NF = 3, GS = 16, LSTR = 16, MODEL_ID = 0;
+    static constexpr int N_ = 8, NTH = 16, NF = 3, GS = 16, LSTR = 16, MODEL_ID = 0, MSPLIT = 0 /* every lane of a row carries a column: no spare lanes to split the recursion over */;
     static_assert(n == 16 && nf <= 48, "one DPP row per problem");
     // per-row LDS map (elements of T)
     static constexpr int O_LC = 0, O_XB = (LC + 1) & ~1, O_WB = O_XB + 16, O_CB = O_WB + 48, O_LIN = O_CB + 16, O_GNB = O_LIN + LSTR * (N + 1),

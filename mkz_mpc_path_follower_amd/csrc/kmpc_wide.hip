@@ -36,8 +36,12 @@ template <typename T, int N> struct WideSolver {
     typedef T real;
     // what kmpc_ipm.h reads: horizon, threads per problem, forms per thread (one), stride of the G_N table, record stride, functor
     static constexpr int N_ = N, NTH = 256, NF = 1, GS = 128, LSTR = WLIN, MODEL_ID = 0;
+    // split adjoint recursion (kmpc_ipm.h, condense_adjoint): threads 128 + j (waves 2 and 3, idle in the unsplit recursion) run the stages below
+    // M = N / 2 for the columns j < 2M while threads j < n run the stages from M up: N / 2 trips instead of N
+    static constexpr int MSPLIT = N / 2, LOW0 = 128, GMS = 64, TM = (2 * MSPLIT + 15) / 16;
+    static_assert(2 * MSPLIT <= GMS && LOW0 + 2 * MSPLIT <= 256 && N % 2 == 0, "one thread per lower column, G_M rows of 64");
     // LDS map (elements of T)
-    static constexpr int O_LC = 0, O_OPB = (LC + 1) & ~1, O_LIN = O_OPB + 2 * 4 * NP + 256 + 3 * 128, O_XB = O_LIN + WLIN * (N + 1), O_WB = O_XB + 128,
+    static constexpr int O_LC = 0, O_OPB = (LC + 1) & ~1, O_LIN = O_OPB + 2 * 4 * NP + 256 + 3 * 128 + 3 * GMS + 64, O_XB = O_LIN + WLIN * (N + 1), O_WB = O_XB + 128,
                          O_CBW = O_WB + 256, O_RED = O_CBW + 4 * 64, O_SINV = O_RED + 2 * 32, O_X2 = O_SINV + 16 * NB, O_X3 = O_X2 + 128,
                          O_GB = O_X3 + 128, O_UB = O_GB + 128, O_CS = O_UB + 128, O_PT = O_CS + 4 * 16, O_KC = O_PT + 32, O_END = O_KC + (sizeof(T) == 8 ? KC_COUNT : 0);
     static constexpr int lds_elems() { return O_END; }
@@ -45,7 +49,7 @@ template <typename T, int N> struct WideSolver {
     STAMP_MEMBERS
     const KP &P;
     int tid, lane, wv, vid;   // vid = tid: the input / form slot of this thread (kmpc_ipm.h)
-    T *Lc, *opb, *pan, *dgs, *sbs, *gnb, *lin, *xb, *wb, *cb, *red, *sinvb, *x2, *x3, *gbl, *gb, *ubl, *cs;
+    T *Lc, *opb, *pan, *dgs, *sbs, *gnb, *gmb, *hm, *lin, *xb, *wb, *cb, *red, *sinvb, *x2, *x3, *gbl, *gb, *ubl, *cs;
     T cu_[1], cl_[1];         // corrector terms of this thread's form
     Coef<T> kc;
     const T *pt, *cwt;
@@ -63,6 +67,8 @@ template <typename T, int N> struct WideSolver {
         pan = opb;                      // the double-buffered Cholesky panel (2 x 4 NP)
         dgs = opb + 2 * 4 * NP; sbs = dgs + 128;  // 2 x n staging of build_tiles
         gnb = sbs + 128;                // terminal sensitivities G_N [3][128], written by linearize, read by every condense of that linearisation
+        gmb = gnb + 3 * 128;            // mid-horizon sensitivities G_M [3][64] of the split recursion, likewise
+        hm = gmb + 3 * GMS;             // what the diagonal entries j < 2M of the image lack (read before the tiles exist: max |sc H_jj|)
         for (int e = tid; e < 16 * NB; e += 256) sinvb[e] = (T)0;
         kc.tab = base + O_KC;
         if (sizeof(T) == 8 && tid < KC_COUNT) const_cast<T *>(kc.tab)[tid] = (T)kmpc_coef[tid];
@@ -114,6 +120,7 @@ template <typename T, int N> struct WideSolver {
     DEV T yoff() const { return z0p[1]; }
     DEV bool rec_writer() const { return wv == 0; }   // every wave holds the same stage data; wave 0 publishes the records
     DEV void refresh_ids() { asm volatile("" : "+v"(tid)); lane = tid & 63; vid = tid; }
+    DEV T *pm(int c) const { return x2 + 64 * c; }     // component c of p_j(M), j < 2M: the substitution buffers x2 | x3 are dead while K is built
     DEV T &cu(int) { return cu_[0]; }                  // corrector terms live in registers (one form per thread)
     DEV T &cl(int) { return cl_[0]; }
     DEV void save_best1(T U) { if (tid < 128) ubl[tid] = U; }
@@ -151,9 +158,14 @@ template <typename T, int N> struct WideSolver {
     {
         const int c = lane & 15;
         const T dt2 = pt[PT_DT2];
+        // split recursion: rows and columns < 2M of the image lack G_M^T P_M -- a rank-4 product, one matrix-core instruction per tile
+        T fa = (T)0;
+        if (ti < TM) fa = ipm::split_fragment_a(*this, ti, c, lane >> 4);
 #pragma unroll
         for (int tj = 0; tj < NTL; ++tj) {
             if (tj <= ti) {
+                acc_t cm = acc_t{0, 0, 0, 0};
+                if (ti < TM) cm = Real<T>::mfma(fa, ipm::split_fragment_b(*this, tj, c, lane >> 4), cm);
                 const int col = 16 * tj + c;
                 const bool colok = col < n;
                 const int cs_ = colok ? col : 0;
@@ -165,7 +177,7 @@ template <typename T, int N> struct WideSolver {
                     T v = (T)0;
                     if (colok && row < n && col <= row) {
                         const T evm = (!(row & 1) && !(col & 1)) ? dt2 : (T)0;
-                        v = fma(evm, cb[row >> 1], colK[row]);
+                        v = fma(evm, cb[row >> 1], colK[row]) + cm[r];
                         if (row == col) v += dgv;
                         if (row == col + 2) v += sbv;
                     } else if (colok && row == n) v = rhv;
@@ -383,7 +395,7 @@ template <typename T, int N> struct WideSolver {
         T hmax = cs[C_HMAX];
         condense_adjoint(sc);
         STAMP(3);
-        if (want_hmax) hmax = max_any(tid < n ? fabs(Lc[offc_rt(tid) + tid]) : (T)0);   // max |sc * H_jj|: scale of the delta_w shift
+        if (want_hmax) hmax = max_any(tid < n ? fabs(Lc[offc_rt(tid) + tid] + (tid < 2 * MSPLIT ? hm[tid] : (T)0)) : (T)0);   // max |sc * H_jj|: scale of the delta_w shift
         bool factored;
         switch (wv) {
             case 0: factored = assemble_factor<0>(sc, reg, want_hmax, hmax); break;
