@@ -227,6 +227,13 @@ template <typename T, int N> struct WideSolver {
             }
         }
     }
+    // solved panel rows of one tile row (component kk of L for row 16 t + c in lane (c, kk): the MFMA fragment layout), published by the wave that
+    // owns the tile row: rows 0..3 in the staging buffers of build_tiles, rows 4..6 in the substitution buffers -- all dead during the factorisation
+    DEV T *pfb(int t) const { return t < 4 ? dgs + 64 * t : x2 + 64 * (t - 4); }
+    // One block-step: every wave factors the 4x4 diagonal block (same data), solves the panel rows of ITS OWN tile rows against it, stores their
+    // L~ entries and publishes their fragments; after a barrier every wave picks up the fragments of the tile columns it needs and runs its
+    // trailing updates.  (Until round 3 every wave solved every tile row it needed a fragment of -- up to seven instead of two -- which made
+    // the block-step three times as long for wave 0 as the second barrier costs.)
     template <int W> DEV bool factor(acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
     {
         constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
@@ -248,39 +255,38 @@ template <typename T, int N> struct WideSolver {
             const T c3 = kk == 0 ? c4.i30 : (kk == 1 ? c4.i31 : (kk == 2 ? c4.i32 : c4.r3));
             const int jc = j0 + kk;
             T *colL = Lc + offc_rt(jc < n ? jc : 0);
-            T pf[NTF];
+            T own[2] = {(T)0, (T)0};
 #pragma unroll
-            for (int t = 0; t < NTF; ++t) {
+            for (int o = 0; o < 2; ++o) {
+                const int t = o == 0 ? R0 : R1;
+                if (t < 0 || t < tcol) continue;             // no second row / finished tile row (wave-uniform)
                 const int row = 16 * t + c;
-                pf[t] = (T)0;
-                if (!(t <= R0 || (t & 3) == W)) continue;   // neither a B fragment of this wave's tiles nor a tile row whose L~ entries it stores
-                if (t < tcol) continue;                      // finished tile rows (wave-uniform)
                 const T *ar = pn + 4 * row;
                 const T av[4] = {ar[0], ar[1], ar[2], ar[3]};
                 T x[4];
                 c4.solve_row(av, x);
                 const T xs = kk == 0 ? x[0] : (kk == 1 ? x[1] : (kk == 2 ? x[2] : x[3]));
                 const bool live = row >= jc && row <= n;
-                pf[t] = live ? xs : (T)0;                       // component kk of L (B fragment of the trailing update)
-                if (live && (t & 3) == W) colL[row] = fma(x[3], c3, fma(x[2], c2, fma(x[1], c1, x[0] * c0)));  // component kk of L~ = L D^-1
+                own[o] = live ? xs : (T)0;                    // component kk of L (fragment of the trailing update)
+                if (live) colL[row] = fma(x[3], c3, fma(x[2], c2, fma(x[1], c1, x[0] * c0)));  // component kk of L~ = L D^-1
+                pfb(t)[lane] = own[o];
             }
-            // the A fragment of tile row R is the B fragment of tile column R (same rows of the solved panel)
-            const T pa0 = pf[R0], pa1 = pf[R1 >= 0 ? R1 : 0];
+            WGSYNC();   // the solved panel is published
             if (j0 + 4 < n) {
                 const int tmin = (j0 + 4) >> 4;  // first tile column that still has live entries
                 if (R0 >= tmin) {
 #pragma unroll
                     for (int t = 0; t <= R0; ++t)
-                        if (t >= tmin) k0[t] = Real<T>::mfma(pa0, -pf[t], k0[t]);
+                        if (t >= tmin) { const T bt = t == R0 ? own[0] : pfb(t)[lane]; k0[t] = Real<T>::mfma(own[0], -bt, k0[t]); }
                 }
                 if (R1 >= tmin) {
 #pragma unroll
                     for (int t = 0; t <= R1; ++t)
-                        if (t >= tmin) k1[t] = Real<T>::mfma(pa1, -pf[t], k1[t]);
+                        if (t >= tmin) { const T bt = t == R1 ? own[1] : pfb(t)[lane]; k1[t] = Real<T>::mfma(own[1], -bt, k1[t]); }
                 }
                 extract_panel<W>(jb + 1, k0, k1);
             }
-            WGSYNC();
+            WGSYNC();   // the next panel is complete (and the fragments have been read)
         }
         return ok;
     }
@@ -312,58 +318,76 @@ template <typename T, int N> struct WideSolver {
     }
 
     // ---- substitutions on the block-LDL^T factor, in wave 0 with two slots per lane (j = lane, 64 + lane) ----------------------------
+    // (the coefficients of the NEXT block are requested before this block's v_readlane -> FMA chain runs: a block step is then that chain, not an LDS round trip)
     DEV void fwd_subst2(T &w0, T &w1)  // L~ y = b
     {
         const bool v1 = 64 + lane < n;
-#pragma nounroll
+        const int r1 = v1 ? 64 + lane : n;
+        T l0[4], l1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { l0[k] = Lc[offc_rt(k) + lane]; l1[k] = Lc[offc_rt(k) + r1]; }
+#pragma unroll 2
         for (int jb = 0; jb < 16; ++jb) {  // blocks in slot 0
             const int j0 = 4 * jb;
-            T l0[4], l1[4];
+            T n0[4], n1[4];
+            const int jn = j0 + 4 < n ? j0 + 4 : j0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { l0[k] = Lc[offc_rt(j0 + k) + lane]; l1[k] = Lc[offc_rt(j0 + k) + (v1 ? 64 + lane : n)]; }
+            for (int k = 0; k < 4; ++k) { n0[k] = Lc[offc_rt(jn + k) + lane]; n1[k] = Lc[offc_rt(jn + k) + r1]; }
             const T t0 = readlane_(w0, j0), t1 = readlane_(w0, j0 + 1), t2 = readlane_(w0, j0 + 2), t3 = readlane_(w0, j0 + 3);
             const T u0 = fma(l0[3], t3, l0[2] * t2) + fma(l0[1], t1, l0[0] * t0);
             const T u1 = fma(l1[3], t3, l1[2] * t2) + fma(l1[1], t1, l1[0] * t0);
             w0 = lane >= j0 + 4 ? w0 - u0 : w0;
             w1 = v1 ? w1 - u1 : w1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { l0[k] = n0[k]; l1[k] = n1[k]; }
         }
-#pragma nounroll
+#pragma unroll 2
         for (int jb = 16; jb < NB - 1; ++jb) {  // blocks in slot 1
             const int j0 = 4 * jb;
-            T l1[4];
+            T n1[4];
+            const int jn = j0 + 4 < n ? j0 + 4 : j0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) l1[k] = Lc[offc_rt(j0 + k) + (v1 ? 64 + lane : n)];
+            for (int k = 0; k < 4; ++k) n1[k] = Lc[offc_rt(jn + k) + r1];
             const int q = j0 - 64;
             const T t0 = readlane_(w1, q), t1 = readlane_(w1, q + 1), t2 = readlane_(w1, q + 2), t3 = readlane_(w1, q + 3);
             const T u1 = fma(l1[3], t3, l1[2] * t2) + fma(l1[1], t1, l1[0] * t0);
             w1 = (v1 && 64 + lane >= j0 + 4) ? w1 - u1 : w1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) l1[k] = n1[k];
         }
     }
     DEV void back_subst2(T &w0, T &w1)  // L~^T x = z
     {
         const bool v1 = 64 + lane < n;
         const T *pc0 = Lc + offc_rt(lane), *pc1 = Lc + offc_rt(v1 ? 64 + lane : 0);
-#pragma nounroll
+        T l0[4], l1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { l0[k] = pc0[4 * (NB - 1) + k]; l1[k] = pc1[4 * (NB - 1) + k]; }
+#pragma unroll 2
         for (int jb = NB - 1; jb >= 16; --jb) {  // blocks in slot 1: rows j0 .. j0+3 of columns i < j0
             const int j0 = 4 * jb, q = j0 - 64;
-            T l0[4], l1[4];
+            T n0[4], n1[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { l0[k] = pc0[j0 + k]; l1[k] = pc1[j0 + k]; }
+            for (int k = 0; k < 4; ++k) { n0[k] = pc0[j0 - 4 + k]; n1[k] = pc1[j0 - 4 + k]; }
             const T t0 = readlane_(w1, q), t1 = readlane_(w1, q + 1), t2 = readlane_(w1, q + 2), t3 = readlane_(w1, q + 3);
             const T u0 = fma(l0[3], t3, l0[2] * t2) + fma(l0[1], t1, l0[0] * t0);
             const T u1 = fma(l1[3], t3, l1[2] * t2) + fma(l1[1], t1, l1[0] * t0);
             w0 -= u0;
             w1 = (v1 && 64 + lane < j0) ? w1 - u1 : w1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { l0[k] = n0[k]; l1[k] = n1[k]; }
         }
-#pragma nounroll
+#pragma unroll 2
         for (int jb = 15; jb >= 1; --jb) {  // blocks in slot 0
             const int j0 = 4 * jb;
-            T l0[4];
+            T n0[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) l0[k] = pc0[j0 + k];
+            for (int k = 0; k < 4; ++k) n0[k] = pc0[j0 - 4 + k];
             const T t0 = readlane_(w0, j0), t1 = readlane_(w0, j0 + 1), t2 = readlane_(w0, j0 + 2), t3 = readlane_(w0, j0 + 3);
             const T u0 = fma(l0[3], t3, l0[2] * t2) + fma(l0[1], t1, l0[0] * t0);
             w0 = lane < j0 ? w0 - u0 : w0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) l0[k] = n0[k];
         }
     }
     DEV T diag_solve1(T y, int j) { return ipm::diag_solve4(sinvb, y, j, lane, n); }  // S^-1 y for the 4x4 block of component j (quad of lanes)
