@@ -21,8 +21,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void kmpc_sched_keys(int B, int N, double dt, const T *z0, const T *ref,
                                                        uint32_t *hist, uint32_t *tag)
 {
+    // ranks inside a bucket come from a workgroup-local histogram (LDS atomics) plus ONE global atomic per bucket and workgroup: with a
+    // global atomic per problem the 256 counters serialised the pre-pass (287 us at B = 262 144 -- 6 % of the N = 8 launch it precedes)
+    __shared__ uint32_t lh[256], lbase[256];
+    lh[threadIdx.x] = 0u;
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B) return;
+    uint32_t bucket = 0u, pos = 0u;
+    if (i < B) {
     // three reference points are enough for a predictor: the spacing of the first segment (references are sampled at
     // constant arclength, ref_gps_traj.py:172-179) and the net heading change between the ends (24 + 16 + 8 B instead of the whole
     // 24 (N+1) B row per problem: 9.3 -> ~3 us at B = 4096)
@@ -32,9 +38,14 @@ __global__ __launch_bounds__(256) void kmpc_sched_keys(int B, int N, double dt, 
     const double key = fabs((double)z0[4 * (size_t)i + 3] - v_ref) + 0.3 * turn;
     int q = (int)(key * 48.0);                 // 1/48 m/s resolution; everything above 5.3 shares the first bucket
     q = q < 0 || !(key == key) ? 0 : (q > 255 ? 255 : q);
-    const uint32_t bucket = 255u - (uint32_t)q;  // bucket 0 = longest
-    const uint32_t pos = atomicAdd(&hist[bucket], 1u);
-    tag[i] = bucket | (pos << 8);
+    bucket = 255u - (uint32_t)q;  // bucket 0 = longest
+    pos = atomicAdd(&lh[bucket], 1u);
+    }
+    __syncthreads();
+    const uint32_t cnt = lh[threadIdx.x];
+    lbase[threadIdx.x] = cnt ? atomicAdd(&hist[threadIdx.x], cnt) : 0u;
+    __syncthreads();
+    if (i < B) tag[i] = bucket | ((lbase[bucket] + pos) << 8);
 }
 
 __global__ __launch_bounds__(256) void kmpc_sched_scatter(int B, const uint32_t *hist, uint32_t *hist_next, const uint32_t *tag,
