@@ -719,7 +719,10 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
             const T slg = sm[0];
             const T phi = sc * Jt - mu * slg;
             const T phi0 = cs[C_PHI0];
-            if (!(okp && phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= eta_phi * alpha * cs[C_DPHI])) {
+            const T dphi = cs[C_DPHI], pred = -alpha * dphi;
+            const bool armijo = phi - phi0 - (T)10 * Real<T>::eps() * fabs(phi0) <= -eta_phi * pred;
+            const bool below_noise = dphi <= (T)0 && pred <= (T)KMPC_NOISE_ACCEPT * Real<T>::eps() * fabs(phi0);   // (kmpc_common.h)
+            if (!(okp && (armijo || below_noise))) {
                 // safeguard: the corrected direction is tried at the full step only; redo the step without the corrector term
                 if (corr_active) {
                     mode = RESTEP;

@@ -78,8 +78,9 @@ def test_solver_options_match_oracle(oracle, N, opt):
     d = make_batch(B, N, cfg_id=9)
     r = _solve(N, d, **opt)
     ro = O.solve_condensed_batch(O.params(N), d["z0"], d["ref"], d["v_target"], d["u_prev"], o=O.opts(**opt), nthreads=8)
-    if "hessian" in opt:   # pure Gauss-Newton stalls on a few large-residual problems (iteration cap, status 1) -- in both solvers
-        assert (r["status"] == ro["status"]).mean() >= 0.97 and (ro["status"] == 0).mean() >= 0.95
+    if "hessian" in opt:   # pure Gauss-Newton cycles on a few large-residual problems (iteration cap, status 1) -- in both solvers (3 to 5 of 96:
+        # whether a cycling run leaves through the line search's "acceptable level" exit is decided by rounding)
+        assert (r["status"] == ro["status"]).mean() >= 0.97 and (ro["status"] == 0).mean() >= 0.93
     else:
         assert (ro["status"] == 0).all() and (r["status"] == 0).all(), (np.bincount(r["status"]), np.bincount(ro["status"]))
     ok = (r["status"] == 0) & (ro["status"] == 0)

@@ -10,7 +10,7 @@ from mkz_mpc_path_follower_amd import BatchMPC
 from mkz_mpc_path_follower_amd.synthetic import make_batch
 b = int(sys.argv[1]); f32 = (sys.argv[2] if len(sys.argv) > 2 else "f64") == "f32"
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 20; B = int(sys.argv[4]) if len(sys.argv) > 4 else 262144
-d = make_batch(B, N, cfg_id=2, dtype=np.float32 if f32 else np.float64)
+d = make_batch(B, N, cfg_id=2, dtype=np.float32 if f32 else np.float64, seed=int(os.environ["QSEED"]) if "QSEED" in os.environ else None)
 s = BatchMPC(N=N, dtype=torch.float32 if f32 else torch.float64)
 L = _lib.load()
 tr = torch.zeros((256, 8), dtype=torch.float64, device="cuda")
