@@ -391,3 +391,15 @@ def test_kinematic_mpc_module_api_and_node_loop():
         beta = np.arctan(1.742 / 2.85 * np.tan(cmd.steer_angle_cmd))
         z = z + 0.1 * np.array([z[3] * np.cos(z[2] + beta), z[3] * np.sin(z[2] + beta), z[3] / 1.742 * np.sin(beta), cmd.accel_cmd])
     assert abs(z[1]) < 0.2 and node.command_stop and cmd.accel_cmd == -1.0
+
+
+def test_line_search_accepts_steps_below_the_merit_noise(oracle):
+    """the GPU side of tests/test_oracle.py::test_line_search_accepts_steps_below_the_merit_noise: the problem that used to limp through 13-18 iterations of
+    failed Armijo tests (and, predicted easy, started in the second round of its launch and ended it) finishes with the checker's iteration count"""
+    d = make_batch(4096, 20, cfg_id=2, seed=20228134)
+    b = 1342
+    one = {k: v[b:b + 1] for k, v in d.items() if k in ("z0", "ref", "v_target", "u_prev")}
+    r = _solve(20, one)
+    ro = oracle.solve_condensed_batch(oracle.params(20), one["z0"], one["ref"], one["v_target"], one["u_prev"], nthreads=1)
+    assert r["status"][0] == 0 and abs(r["cost"][0] - ro["cost"][0]) < 1e-9
+    assert r["iters"][0] <= 7 and abs(int(r["iters"][0]) - int(ro["iters"][0])) <= 1

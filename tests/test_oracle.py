@@ -198,3 +198,17 @@ def test_warm_start_reaches_same_optimum(oracle):
     warm = O.solve_condensed(p, q, O.opts(warm=1), U0=cold["U"])
     assert warm["status"] == 0 and abs(warm["cost"] - cold["cost"]) < 1e-6 * max(1, cold["cost"])
     assert warm["iters"] <= cold["iters"]
+
+
+def test_line_search_accepts_steps_below_the_merit_noise(oracle):
+    """Round 3: near a low-cost optimum the predicted decrease of phi_mu falls below the noise of its evaluation (~60 eps |phi|) and the Armijo
+    test used to fail on rounding alone -- this problem (cost 2.17, error 3.5e-8 after five iterations) then took 8 iterations with 96 trial
+    roll-outs, the same problem on the GPU 13-18 iterations and set the time of its 4096-problem launch.  With the noise-aware acceptance
+    (KMPC_NOISE_ACCEPT, same rule in csrc/kmpc_ipm.h) it is done in 6 iterations with one trial each."""
+    from mkz_mpc_path_follower_amd.synthetic import make_batch
+    O = oracle
+    d = make_batch(4096, 20, cfg_id=2, seed=20228134)
+    b = 1342
+    r = O.solve_condensed_batch(O.params(20), d["z0"][b:b + 1], d["ref"][b:b + 1], d["v_target"][b:b + 1], d["u_prev"][b:b + 1], nthreads=1)
+    assert r["status"][0] == 0 and abs(r["cost"][0] - 2.169311511528) < 1e-9
+    assert r["iters"][0] <= 7 and r["n_ls"][0] <= 8, (r["iters"], r["n_ls"])
