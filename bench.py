@@ -394,6 +394,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank control flow on a one-GPU box)")
     a = ap.parse_args()
+    # dmabuf IPC only on this pool (RCCL / cross-process tensors fail with hipIpcGetMemHandle otherwise): already exported on the boxes; set before the
+    # first HIP call in case a launcher dropped it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run child) BEFORE any
