@@ -195,35 +195,24 @@ template <typename T, int N> struct WideSolver {
         WGSYNC();  // dgs / sbs / the odd rows of the image have been consumed: the panel and the factor may overwrite them
     }
 
-    // ---- blocked Cholesky on the matrix cores (block-LDL^T form, see kmpc_fast.hip), one barrier per 4-column block-step ---------
-    template <int W> DEV void extract_panel(int jb, const acc_t (&k0)[Rows<W>::N0], const acc_t (&k1)[Rows<W>::N1])
+    // ---- blocked Cholesky on the matrix cores (block-LDL^T form, see kmpc_fast.hip), two barriers per 4-column block-step ---------
+    // The panel of block-step jb (columns 4 jb .. 4 jb + 3 of the current Schur complement) goes to LDS from the tile column TC that holds it.
+    // TC is a TEMPLATE parameter: the factorisation is unrolled over the tile columns (four block-steps each in a rolled loop), so tile indices,
+    // liveness tests and the panel's source registers are all static.  (Until round 3 the tile column was a run-time value and the panel's
+    // tile was picked by value selects -- 48 v_cndmask per block-step in wave 0; a branch per tile column had ended in scratch-resident tiles.)
+    template <int W, int TC> DEV void extract_panel(int jb, const acc_t (&k0)[Rows<W>::N0], const acc_t (&k1)[Rows<W>::N1])
     {
         constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
-        const int c = lane & 15, j0 = 4 * jb, tcol = j0 >> 4, kp = c - (j0 & 15);
+        const int c = lane & 15, j0 = 4 * jb, kp = c - (j0 & 15);
         T *pn = pan + (jb & 1) * 4 * NP;
-        // the tile of column tcol is picked by VALUE selects: a branch per tile column ends, after the optimiser's block merging, in a
-        // phi over the addresses of the tile registers, which keeps every tile in scratch memory
-        acc_t v0 = k0[0], v1 = k1[0];
-#pragma unroll
-        for (int tc = 1; tc <= R0; ++tc) {
-            const bool hit = tcol == tc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v0[r] = hit ? k0[tc][r] : v0[r];
-        }
-#pragma unroll
-        for (int tc = 1; tc <= R1; ++tc) {
-            const bool hit = tcol == tc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v1[r] = hit ? k1[tc][r] : v1[r];
-        }
         if (kp >= 0 && kp < 4) {
-            if (tcol <= R0) {
+            if constexpr (TC <= R0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pn[4 * (16 * R0 + Real<T>::row_of(lane, r)) + kp] = v0[r];
+                for (int r = 0; r < 4; ++r) pn[4 * (16 * R0 + Real<T>::row_of(lane, r)) + kp] = k0[TC][r];
             }
-            if (R1 >= 0 && tcol <= R1) {
+            if constexpr (R1 >= 0 && TC <= R1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pn[4 * (16 * R1 + Real<T>::row_of(lane, r)) + kp] = v1[r];
+                for (int r = 0; r < 4; ++r) pn[4 * (16 * R1 + Real<T>::row_of(lane, r)) + kp] = k1[TC][r];
             }
         }
     }
@@ -234,19 +223,17 @@ template <typename T, int N> struct WideSolver {
     // L~ entries and publishes their fragments; after a barrier every wave picks up the fragments of the tile columns it needs and runs its
     // trailing updates.  (Until round 3 every wave solved every tile row it needed a fragment of -- up to seven instead of two -- which made
     // the block-step three times as long for wave 0 as the second barrier costs.)
-    template <int W> DEV bool factor(acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
+    template <int W, int TC> DEV bool factor_column(acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
     {
         constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
+        constexpr int STEPS = NB - 4 * TC < 4 ? NB - 4 * TC : 4;   // block-steps inside this tile column (the last one may be partial)
         const int c = lane & 15, kk = lane >> 4;
-        extract_panel<W>(0, k0, k1);
-        WGSYNC();
-        bool ok = true;
 #pragma nounroll
-        for (int jb = 0; jb < NB; ++jb) {
-            const int j0 = 4 * jb, tcol = j0 >> 4;
+        for (int s4 = 0; s4 < STEPS; ++s4) {
+            const int jb = 4 * TC + s4, j0 = 4 * jb;
             const T *pn = pan + (jb & 1) * 4 * NP;
             const ipm::Chol4<T> c4 = ipm::factor_diag4(ipm::load_diag4(pn + 4 * j0));
-            if (!c4.ok) { ok = false; break; }  // not positive definite (same data in every wave)
+            if (!c4.ok) return false;  // not positive definite (same data in every wave)
             if (tid == 0) c4.store_inv(sinvb + 16 * jb);
             // column kk of D_j^-1 for this lane's component of L~
             const T c0 = kk == 0 ? c4.r0 : (T)0;
@@ -258,8 +245,9 @@ template <typename T, int N> struct WideSolver {
             T own[2] = {(T)0, (T)0};
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
+                constexpr int dummy = 0; (void)dummy;
                 const int t = o == 0 ? R0 : R1;
-                if (t < 0 || t < tcol) continue;             // no second row / finished tile row (wave-uniform)
+                if (t < TC) continue;                         // no second row (R1 = -1) / finished tile row: static after unrolling
                 const int row = 16 * t + c;
                 const T *ar = pn + 4 * row;
                 const T av[4] = {ar[0], ar[1], ar[2], ar[3]};
@@ -273,22 +261,36 @@ template <typename T, int N> struct WideSolver {
             }
             WGSYNC();   // the solved panel is published
             if (j0 + 4 < n) {
-                const int tmin = (j0 + 4) >> 4;  // first tile column that still has live entries
-                if (R0 >= tmin) {
+                const bool same = s4 < 3;   // the next panel still lies in tile column TC (and that column still has live entries)
+                if constexpr (R0 >= TC) {
+                    if (same) { const T bt = TC == R0 ? own[0] : pfb(TC)[lane]; k0[TC] = Real<T>::mfma(own[0], -bt, k0[TC]); }
 #pragma unroll
-                    for (int t = 0; t <= R0; ++t)
-                        if (t >= tmin) { const T bt = t == R0 ? own[0] : pfb(t)[lane]; k0[t] = Real<T>::mfma(own[0], -bt, k0[t]); }
+                    for (int t = TC + 1; t <= R0; ++t) { const T bt = t == R0 ? own[0] : pfb(t)[lane]; k0[t] = Real<T>::mfma(own[0], -bt, k0[t]); }
                 }
-                if (R1 >= tmin) {
+                if constexpr (R1 >= TC) {
+                    if (same) { const T bt = TC == R1 ? own[1] : pfb(TC)[lane]; k1[TC] = Real<T>::mfma(own[1], -bt, k1[TC]); }
 #pragma unroll
-                    for (int t = 0; t <= R1; ++t)
-                        if (t >= tmin) { const T bt = t == R1 ? own[1] : pfb(t)[lane]; k1[t] = Real<T>::mfma(own[1], -bt, k1[t]); }
+                    for (int t = TC + 1; t <= R1; ++t) { const T bt = t == R1 ? own[1] : pfb(t)[lane]; k1[t] = Real<T>::mfma(own[1], -bt, k1[t]); }
                 }
-                extract_panel<W>(jb + 1, k0, k1);
+                if (same) extract_panel<W, TC>(jb + 1, k0, k1);
+                else extract_panel<W, (TC + 1 < NTF ? TC + 1 : TC)>(jb + 1, k0, k1);
             }
             WGSYNC();   // the next panel is complete (and the fragments have been read)
         }
-        return ok;
+        return true;
+    }
+    template <int W, int TC> DEV bool factor_from(acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
+    {
+        if constexpr (4 * TC < NB) {
+            if (!factor_column<W, TC>(k0, k1)) return false;
+            return factor_from<W, TC + 1>(k0, k1);
+        } else return true;
+    }
+    template <int W> DEV bool factor(acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
+    {
+        extract_panel<W, 0>(0, k0, k1);
+        WGSYNC();
+        return factor_from<W, 0>(k0, k1);
     }
 
     // condense + (max |sc H_jj|) + KKT assembly + factorisation for the tile rows of wave W
