@@ -232,7 +232,17 @@ template <typename T, int N> struct WideSolver {
         for (int s4 = 0; s4 < STEPS; ++s4) {
             const int jb = 4 * TC + s4, j0 = 4 * jb;
             const T *pn = pan + (jb & 1) * 4 * NP;
-            const ipm::Chol4<T> c4 = ipm::factor_diag4(ipm::load_diag4(pn + 4 * j0));
+            const ipm::Diag4<T> dd = ipm::load_diag4(pn + 4 * j0);
+            // the panel rows of this wave's tile rows do not depend on the diagonal factor until the solve: request them now
+            T av[2][4];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int t = o == 0 ? R0 : R1;
+                const T *ar = pn + 4 * (16 * (t >= TC ? t : TC) + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) av[o][k] = ar[k];
+            }
+            const ipm::Chol4<T> c4 = ipm::factor_diag4(dd);
             if (!c4.ok) return false;  // not positive definite (same data in every wave)
             if (tid == 0) c4.store_inv(sinvb + 16 * jb);
             // column kk of D_j^-1 for this lane's component of L~
@@ -249,10 +259,8 @@ template <typename T, int N> struct WideSolver {
                 const int t = o == 0 ? R0 : R1;
                 if (t < TC) continue;                         // no second row (R1 = -1) / finished tile row: static after unrolling
                 const int row = 16 * t + c;
-                const T *ar = pn + 4 * row;
-                const T av[4] = {ar[0], ar[1], ar[2], ar[3]};
                 T x[4];
-                c4.solve_row(av, x);
+                c4.solve_row(av[o], x);
                 const T xs = kk == 0 ? x[0] : (kk == 1 ? x[1] : (kk == 2 ? x[2] : x[3]));
                 const bool live = row >= jc && row <= n;
                 own[o] = live ? xs : (T)0;                    // component kk of L (fragment of the trailing update)
