@@ -460,6 +460,9 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
        cost is a sum of C e^2 terms whose e = x - x_ref carries eps |x|, |x| >> |e|, so phi is resolved to ~50-70 eps |phi|, not to the
        10 eps of Ipopt's slack): near a low-cost optimum the Armijo test otherwise fails on rounding alone, the search backtracks max_ls
        times and takes a 1e-5 step "by luck" -- ~100 wasted roll-outs per solve on ~0.25 % of the problems.  Experiment override: KMPC_X_NOISE. */
+    const double x_decay = getenv("KMPC_X_DECAY") ? atof(getenv("KMPC_X_DECAY")) : 3.0;
+    const int x_zero_after = getenv("KMPC_X_ZEROAFTER") ? atoi(getenv("KMPC_X_ZEROAFTER")) : 0;
+    int n_first_ok = 0;
     const double k_noise = getenv("KMPC_X_NOISE") ? atof(getenv("KMPC_X_NOISE")) : KMPC_NOISE_ACCEPT;
     const double kappa_rd_nc = getenv("KMPC_X_KRDNC") ? atof(getenv("KMPC_X_KRDNC")) : 1e2;
     /* 2 = hybrid: Gauss-Newton fallback until the exact Hessian has failed gn_switch times, delta_w shift from then on */
@@ -587,8 +590,11 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
            non-convex region the delta_w = 0 attempt fails iteration after iteration -- up to 40 % of the factorisations of the
            slowest problems -- while a decaying shift costs nothing near the solution (dropped below 1e-9 * max|H_jj|) */
         if (!use_gn && indef_strategy == 1 && dw_spec > 0.0) {
-            reg = dw_spec / 3.0;
+            reg = dw_spec / x_decay;
             if (reg < 1e-9 * hmax_prev) reg = 0.0;
+            /* experiment (KMPC_X_ZEROAFTER = k, default off): after k first-trial successes in a row retry delta_w = 0 first.  Measured on 12 pooled
+               batches: E[worst of 4096] 26.06 -> 25.3 iteration-equivalents at k = 2..3, mean unchanged -- too little to move the kernels for */
+            if (x_zero_after > 0 && n_first_ok >= x_zero_after) reg = 0.0;
         }
         if (!use_gn && indef_strategy == 1) hmax_prev = hmax;
         for (int attempt = 0;; ++attempt) {
@@ -597,7 +603,12 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
             for (int f = 0; f < nf; ++f) w[f] = lu[f] / su[f] + ll[f] / sl[f];
             forms_gram_add(&F, w, K);
             for (int j = 0; j < n; ++j) K[j * n + j] += reg;
-            if (chol(K, n) == 0) { if (!use_gn && reg > 0.0) dw_last = reg; if (!use_gn) dw_spec = reg; reg_final = use_gn ? 0.0 : reg / fmax(hmax, 1e-300); break; }
+            if (chol(K, n) == 0) {
+                if (!use_gn && reg > 0.0) dw_last = reg;
+                if (!use_gn) { dw_spec = reg; n_first_ok = attempt == 0 ? n_first_ok + 1 : 0; }
+                reg_final = use_gn ? 0.0 : reg / fmax(hmax, 1e-300);
+                break;
+            }
             ++n_refac;
             if (!use_gn && indef_strategy == 1) {
                 if (reg == 0.0) reg = dw_last > 0.0 ? fmax(1e-10 * hmax, dw_last / 3.0) : 1e-2 * hmax;
