@@ -463,6 +463,8 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
     const double x_decay = getenv("KMPC_X_DECAY") ? atof(getenv("KMPC_X_DECAY")) : 3.0;
     const int x_zero_after = getenv("KMPC_X_ZEROAFTER") ? atoi(getenv("KMPC_X_ZEROAFTER")) : 0;
     int n_first_ok = 0, full_prev = 0;
+    const double x_sigexp = getenv("KMPC_X_SIGEXP") ? atof(getenv("KMPC_X_SIGEXP")) : 3.0;   /* experiment knobs: Mehrotra exponent, fraction to the boundary */
+    const double x_tau = getenv("KMPC_X_TAU") ? atof(getenv("KMPC_X_TAU")) : tau_min;
     const int x_gate = getenv("KMPC_X_GATE") ? atoi(getenv("KMPC_X_GATE")) : 2;
     double err_p1 = INFINITY, err_p2 = INFINITY;
     const double k_noise = getenv("KMPC_X_NOISE") ? atof(getenv("KMPC_X_NOISE")) : KMPC_NOISE_ACCEPT;
@@ -661,11 +663,11 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
             }
             mucur /= 2.0 * nf;
             muaff /= 2.0 * nf;
-            const double r3 = muaff / mucur, sigma = fmin(1.0, r3 * r3 * r3);
+            const double r3 = muaff / mucur, sigma = fmin(1.0, x_sigexp == 3.0 ? r3 * r3 * r3 : pow(r3, x_sigexp));
             mu = fmax(mu_min, sigma * mucur);
             mu = fmax(mu, fmin(mucur, rdmax / s_d / ((!use_gn && reg > 0.0) ? kappa_rd_nc : ((indef_strategy == 1 || !(x_gate == 1 ? full_prev : (x_gate == 2 ? (err0 < err_p1 && err_p1 < err_p2) : 1))) ? kappa_rd : kappa_rd_easy))));
         }
-        const double tau = fmax(tau_min, 1.0 - mu);
+        const double tau = fmax(x_tau, 1.0 - mu);
         int accepted = 0;
         double alpha = 0.0, ap = 1.0, ad = 1.0;
         for (int pass = 0; pass < 2 && !accepted; ++pass) {
