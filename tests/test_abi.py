@@ -64,3 +64,26 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 for bad in ("import oracle", "from oracle", "libkmpc_oracle", "oracle/", "kmpc_condensed_solve", "kmpc_nlp.h"):
                     assert bad not in src, (f, bad)
+
+
+def test_makefile_lists_every_included_header():
+    """An object file must be rebuilt when a header it includes changes: the generic kernel once kept running an older kmpc_ipm.h because
+    its Makefile rule did not list it (round 3; caught by the kernels' iteration counts parting from the CPU checker's)."""
+    csrc = os.path.join(ROOT, "mkz_mpc_path_follower_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+
+    def includes(path, seen):
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(path).read()):
+            f = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+            if f not in seen and os.path.exists(f):
+                seen.add(f)
+                includes(f, seen)
+        return seen
+
+    rules = dict(re.findall(r"^(kmpc_\w+\.o):\s*(.*)$", mk, flags=re.M))
+    assert len(rules) >= 8
+    for obj, deps in rules.items():
+        src = os.path.join(csrc, obj[:-2] + ".hip")
+        listed = {os.path.normpath(os.path.join(csrc, d)) for d in deps.split()}
+        missing = [os.path.relpath(f, csrc) for f in includes(src, set()) if f not in listed]
+        assert not missing, (obj, missing)
