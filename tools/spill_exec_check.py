@@ -37,7 +37,7 @@ def kernels(asm):
             continue
         if name is None:
             continue
-        if l.startswith("\t.size\t" + name) or l.strip() == "s_endpgm" and False:
+        if l.startswith("\t.size\t" + name):
             yield name, body
             name = None
             continue
@@ -45,7 +45,6 @@ def kernels(asm):
 
 
 SCR = re.compile(r"\s*scratch_(load|store)_(dword|dwordx2|dwordx3|dwordx4|short|ubyte|byte)\S*\s+(.*)")
-WIDTH = {"dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16, "short": 2, "ubyte": 1, "byte": 1}
 
 
 def check_kernel(lines):
