@@ -403,3 +403,12 @@ def test_line_search_accepts_steps_below_the_merit_noise(oracle):
     ro = oracle.solve_condensed_batch(oracle.params(20), one["z0"], one["ref"], one["v_target"], one["u_prev"], nthreads=1)
     assert r["status"][0] == 0 and abs(r["cost"][0] - ro["cost"][0]) < 1e-9
     assert r["iters"][0] <= 7 and abs(int(r["iters"][0]) - int(ro["iters"][0])) <= 1
+
+
+def test_barrier_floor_gate_keeps_the_cycling_problem(oracle):
+    """the GPU side of tests/test_oracle.py::test_barrier_floor_gate_keeps_the_cycling_problem (four-wave kernel, N = 50)"""
+    d = make_batch(4096, 50, cfg_id=5)
+    b = 1010
+    one = {k: v[b:b + 1] for k, v in d.items() if k in ("z0", "ref", "v_target", "u_prev")}
+    r = _solve(50, one)
+    assert r["status"][0] == 0 and r["iters"][0] <= 20 and abs(r["cost"][0] - 802.0932995) < 1e-5, (r["status"], r["iters"], r["cost"])

@@ -212,3 +212,15 @@ def test_line_search_accepts_steps_below_the_merit_noise(oracle):
     r = O.solve_condensed_batch(O.params(20), d["z0"][b:b + 1], d["ref"][b:b + 1], d["v_target"][b:b + 1], d["u_prev"][b:b + 1], nthreads=1)
     assert r["status"][0] == 0 and abs(r["cost"][0] - 2.169311511528) < 1e-9
     assert r["iters"][0] <= 7 and r["n_ls"][0] <= 8, (r["iters"], r["n_ls"])
+
+
+def test_barrier_floor_gate_keeps_the_cycling_problem(oracle):
+    """Round 3: the Mehrotra target's floor mu >= rd / 1000 is dropped (outside shift mode) while the optimality error fell in each of the last two
+    iterations.  Without any floor there this problem of the N = 50 bench batch cycles to the iteration cap (mu collapses to 1e-8 at error 5, a 3 % step,
+    the error rebounds); its error never falls twice in a row, so the gate keeps its floor: Optimal in 15 iterations, cost 802.09 (the cycle sat at 814)."""
+    from mkz_mpc_path_follower_amd.synthetic import make_batch
+    O = oracle
+    d = make_batch(4096, 50, cfg_id=5)
+    b = 1010
+    r = O.solve_condensed_batch(O.params(50), d["z0"][b:b + 1], d["ref"][b:b + 1], d["v_target"][b:b + 1], d["u_prev"][b:b + 1], nthreads=1)
+    assert r["status"][0] == 0 and r["iters"][0] <= 20 and abs(r["cost"][0] - 802.0932995) < 1e-5, (r["status"], r["iters"], r["cost"])
