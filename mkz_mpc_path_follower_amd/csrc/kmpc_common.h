@@ -12,12 +12,12 @@
 // Tuned constants of the non-convex phase (kmpc_ipm.h and the generic kernel; the CPU checker carries the same values).  Chosen on the
 // pooled worst-of-4096 statistics of 48 seeded 4096-problem batches: shift growth after a failed first trial
 // 8 -> 3 (the first trial is last/3, so x3 returns to the shift that worked last iteration instead of overshooting it 2.7-fold),
-// barrier floor in shifted iterations rd/1000 -> rd/100.
+// barrier floor in shifted iterations rd/1000 -> rd/100 (-> rd/40 later in round 3).
 #ifndef KMPC_IKRD
 #define KMPC_IKRD 1e-3
 #endif
 #ifndef KMPC_IKRD_NC
-#define KMPC_IKRD_NC 1e-2
+#define KMPC_IKRD_NC 2.5e-2   // (rd/100 until the hybrid strategy switched at the first failure; re-measured on 12 pooled batches: rd/40)
 #endif
 #ifndef KMPC_DW_GROW
 #define KMPC_DW_GROW 3

@@ -463,12 +463,13 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
     const double x_decay = getenv("KMPC_X_DECAY") ? atof(getenv("KMPC_X_DECAY")) : 3.0;
     const int x_zero_after = getenv("KMPC_X_ZEROAFTER") ? atoi(getenv("KMPC_X_ZEROAFTER")) : 0;
     int n_first_ok = 0, full_prev = 0;
+    const double x_dw0 = getenv("KMPC_X_DW0") ? atof(getenv("KMPC_X_DW0")) : 1e-2;   /* experiment: first shift relative to max |sc H_jj| */
     const double x_sigexp = getenv("KMPC_X_SIGEXP") ? atof(getenv("KMPC_X_SIGEXP")) : 3.0;   /* experiment knobs: Mehrotra exponent, fraction to the boundary */
     const double x_tau = getenv("KMPC_X_TAU") ? atof(getenv("KMPC_X_TAU")) : tau_min;
     const int x_gate = getenv("KMPC_X_GATE") ? atoi(getenv("KMPC_X_GATE")) : 2;
     double err_p1 = INFINITY, err_p2 = INFINITY;
     const double k_noise = getenv("KMPC_X_NOISE") ? atof(getenv("KMPC_X_NOISE")) : KMPC_NOISE_ACCEPT;
-    const double kappa_rd_nc = getenv("KMPC_X_KRDNC") ? atof(getenv("KMPC_X_KRDNC")) : 1e2;
+    const double kappa_rd_nc = getenv("KMPC_X_KRDNC") ? atof(getenv("KMPC_X_KRDNC")) : 40.0;   /* (1e2 until the first-failure switch; re-measured: 10 ... 300) */
     /* 2 = hybrid: Gauss-Newton fallback until the exact Hessian has failed gn_switch times, delta_w shift from then on */
     const int indef_cfg = o->indef_strategy >= 0 ? o->indef_strategy : 2;
     int indef_strategy = indef_cfg == 2 ? 0 : indef_cfg, n_fail = 0;
@@ -626,7 +627,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
             }
             ++n_refac;
             if (!use_gn && indef_strategy == 1) {
-                if (reg == 0.0) reg = dw_last > 0.0 ? fmax(1e-10 * hmax, dw_last / 3.0) : 1e-2 * hmax;
+                if (reg == 0.0) reg = dw_last > 0.0 ? fmax(1e-10 * hmax, dw_last / 3.0) : x_dw0 * hmax;
                 else reg *= (dw_last > 0.0 ? dw_grow : 10.0);
                 if (reg > 1e2 * hmax) { use_gn = 1; reg = 0.0; }
             } else if (!use_gn) {
