@@ -891,8 +891,9 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                         if (reg > (T)1e2 * hmax) { use_exact = false; reg = 0; s.drop_second_order(); }
                     } else if (use_exact) {
                         use_exact = false; gn_hold = 2; s.drop_second_order();
-                        // (hybrid: shift mode from the first failure up to N = 28, from the second beyond -- pooled worst-of-4096 statistics)
-                        if (indef_cfg == 2 && ++n_fail >= (N >= 32 ? 2 : 1)) { indef = 1; gn_hold = 0; }
+                        // (hybrid: shift mode from the first failure up to N = 28 on cold starts, from the second beyond and on warm starts -- pooled
+                        // worst-of-4096 statistics; a warm start from a poor point begins at mu = 1e-6, where shift mode right away stalls)
+                        if (indef_cfg == 2 && ++n_fail >= ((N >= 32 || warm) ? 2 : 1)) { indef = 1; gn_hold = 0; }
                     } else reg = reg == (T)0 ? (T)1e-8 : reg * (T)100;  // last resort: shift the Gauss-Newton matrix
                     mode = REFACTOR;
                 } else { status = 3; mode = FINAL; final_reuse = true; }

@@ -476,7 +476,8 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
     /* Round 3: one failure is enough up to N = 28 -- pooled worst-of-4096 iteration-equivalents 25.75 -> 23.52 at N = 20, 22.9 -> 20.6 at N = 12,
        30.5 -> 29.1 at N = 28 with the mean unchanged (+0.1 ... 0.5 %); at N = 50 the mean would rise 4.6 % for 5 % off the tail, and that
        config is throughput-bound, so the long horizons keep two.  Experiment override: KMPC_X_GNSWITCH. */
-    const int gn_switch = getenv("KMPC_X_GNSWITCH") ? atoi(getenv("KMPC_X_GNSWITCH")) : (N >= 32 ? 2 : 1);
+    const int gn_switch = getenv("KMPC_X_GNSWITCH") ? atoi(getenv("KMPC_X_GNSWITCH")) : ((N >= 32 || o->warm) ? 2 : 1);   /* (a warm start from a poor point begins at mu = 1e-6: shift mode right away stalls there --
+                                                                                                        3 of 32768 wrong-point warm starts hit the iteration cap, mean 10.7 -> 12.4 iterations; tools/warm_probe.py) */
     /* Mehrotra safeguards: the barrier target may not drop below (scaled dual infeasibility)/kappa_rd while that exceeds the
        current complementarity (a Gauss-Newton step does not reduce the dual residual the way an LP/QP step does); and the
        corrected direction is only tried at the full fraction-to-the-boundary step */
