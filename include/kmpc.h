@@ -69,7 +69,7 @@ typedef struct kmpc_config {
     double tol;          /* Ipopt tol (scaled optimality error), 1e-8 */
     double mu_init;      /* barrier parameter of a cold start (default 1.0; Ipopt's is 0.1) */
     double bound_relax;  /* Ipopt bound_relax_factor, 1e-8 */
-    double warm_push;    /* weight of the interior point blended into a warm start (default 1e-4) */
+    double warm_push;    /* weight of the interior point blended into a warm start (default 1e-5) */
     double warm_mu;      /* mu_init used with a warm start (default 1e-6) */
     int32_t max_ls;      /* back-tracking trial points per iteration */
     int32_t kernel_variant; /* 0 = auto: the compile-time-horizon kernel built for N (see N; at N = 8 batches of 1024 problems or more run the

@@ -19,7 +19,7 @@ void kmpc_opts_default(kmpc_opts *o)
     o->mu_init = 1.0; /* Ipopt default 0.1; 1.0 measured better at N = 8, 20, 50 (mean -5 %, max 45 -> 31 at N = 20) */
     o->bound_relax = 1e-8;
     o->warm = 0;
-    o->warm_push = 1e-4;
+    o->warm_push = 1e-5;
     o->warm_mu = 1e-6;
     o->max_ls = 40;
     o->mu_strategy = -1;

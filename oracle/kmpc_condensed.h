@@ -31,7 +31,7 @@ typedef struct kmpc_opts {
     double mu_init;      /* cold-start barrier parameter (1.0; Ipopt's default is 0.1) */
     double bound_relax;  /* Ipopt bound_relax_factor = 1e-8 */
     int warm;            /* 1: U on entry is a warm start (blended into the interior) */
-    double warm_push;    /* weight of the analytic interior point in the blend (0.01) */
+    double warm_push;    /* weight of the analytic interior point in the blend (1e-5) */
     double warm_mu;      /* mu_init used with a warm start */
     int max_ls;          /* back-tracking steps */
     int mu_strategy;     /* 0 = Ipopt's monotone Fiacco-McCormick default, 1 = Mehrotra predictor-corrector (adaptive),

@@ -7,7 +7,7 @@ from mkz_mpc_path_follower_amd.synthetic import make_batch
 for N in (8, 20):
     B = 32768
     a = make_batch(B, N, cfg_id=5); b = make_batch(B, N, cfg_id=6)
-    for wm, wp in ((1e-3, 1e-2), (1e-6, 1e-4), (1e-7, 1e-5)):
+    for wm, wp in [tuple(float(x) for x in c.split(",")) for c in os.environ.get("WARM_SCAN", "1e-3,1e-2;1e-6,1e-4;1e-7,1e-5").split(";")]:
         s = BatchMPC(N=N, warm_mu=wm, warm_push=wp)
         oa = s.solve(a["z0"], a["ref"], a["v_target"], a["u_prev"], want_U=True)
         cold = s.solve(b["z0"], b["ref"], b["v_target"], b["u_prev"])
