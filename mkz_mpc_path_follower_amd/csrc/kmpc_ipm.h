@@ -625,7 +625,7 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
     bool fv[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) { const int f = s.vid + NTH * i; fv[i] = f < nf; lu[i] = ll[i] = sup[i] = slo[i] = isu[i] = isl[i] = aut[i] = (T)0; }
-    int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0;
+    int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0, n_first_ok = 0;
     T *cs = s.cs;
     cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_MUF] = 0; cs[C_PHI0] = 0; cs[C_DPHI] = 0;
     cs[C_AD] = 0; cs[C_J] = 0; cs[C_LGS] = 0; cs[C_JP] = (T)1e30; cs[C_EP1] = (T)1e30; cs[C_EP2] = (T)1e30;
@@ -866,7 +866,9 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 use_exact = exact && gn_hold == 0; reg = 0; attempt = 0;  // GN is held for 2 iterations after an indefinite exact Hessian
                 if (gn_hold > 0) --gn_hold;
                 // in shift mode the previous iteration's delta_w / 3 is the first trial (dropped below 1e-9 * max|H_jj|)
-                if (use_exact && indef == 1 && cs[C_DWS] > (T)0) { reg = cs[C_DWS] / (T)3; if (reg < (T)1e-9 * cs[C_HMAX]) reg = 0; }
+                // ... and after two first-trial successes in a row the unshifted matrix is tried first again: a decaying shift slows the end game of the solves
+                // that have left the non-convex region
+                if (use_exact && indef == 1 && cs[C_DWS] > (T)0) { reg = cs[C_DWS] / (T)3; if (reg < (T)1e-9 * cs[C_HMAX] || n_first_ok >= 2) reg = 0; }
                 first_attempt = true;
                 STAMP_AT(s, 2);
             }
@@ -902,7 +904,7 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 continue;
             }
             if (use_exact && reg > (T)0) cs[C_DWL] = reg;
-            if (use_exact) cs[C_DWS] = reg;
+            if (use_exact) { cs[C_DWS] = reg; n_first_ok = attempt == 0 ? n_first_ok + 1 : 0; }
 #pragma unroll
             for (int i = 0; i < NF; ++i) s.cu(i) = s.cl(i) = (T)0;
             corr_active = false;

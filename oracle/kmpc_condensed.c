@@ -461,8 +461,9 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
        10 eps of Ipopt's slack): near a low-cost optimum the Armijo test otherwise fails on rounding alone, the search backtracks max_ls
        times and takes a 1e-5 step "by luck" -- ~100 wasted roll-outs per solve on ~0.25 % of the problems.  Experiment override: KMPC_X_NOISE. */
     const double x_decay = getenv("KMPC_X_DECAY") ? atof(getenv("KMPC_X_DECAY")) : 3.0;
-    const int x_zero_after = getenv("KMPC_X_ZEROAFTER") ? atoi(getenv("KMPC_X_ZEROAFTER")) : 0;
+    const int x_zero_after = getenv("KMPC_X_ZEROAFTER") ? atoi(getenv("KMPC_X_ZEROAFTER")) : 2;
     int n_first_ok = 0, full_prev = 0;
+    const int x_leave = getenv("KMPC_X_LEAVE") ? atoi(getenv("KMPC_X_LEAVE")) : 0;
     const double x_dw0 = getenv("KMPC_X_DW0") ? atof(getenv("KMPC_X_DW0")) : 1e-2;   /* experiment: first shift relative to max |sc H_jj| */
     const double x_sigexp = getenv("KMPC_X_SIGEXP") ? atof(getenv("KMPC_X_SIGEXP")) : 3.0;   /* experiment knobs: Mehrotra exponent, fraction to the boundary */
     const double x_tau = getenv("KMPC_X_TAU") ? atof(getenv("KMPC_X_TAU")) : tau_min;
@@ -609,8 +610,10 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
         if (!use_gn && indef_strategy == 1 && dw_spec > 0.0) {
             reg = dw_spec / x_decay;
             if (reg < 1e-9 * hmax_prev) reg = 0.0;
-            /* experiment (KMPC_X_ZEROAFTER = k, default off): after k first-trial successes in a row retry delta_w = 0 first.  Measured on 12 pooled
-               batches: E[worst of 4096] 26.06 -> 25.3 iteration-equivalents at k = 2..3, mean unchanged -- too little to move the kernels for */
+            /* after two first-trial successes in a row the unshifted matrix is tried first again (KMPC_X_ZEROAFTER = k, 0 = never): a decaying shift
+               slows the end game of the solves that left the non-convex region (error x8 per iteration over the last ten iterations of the slowest
+               problem of the bench batch).  12 pooled batches: E[worst of 4096] 22.40 -> 21.71 at N = 20, 19.1 -> 18.2 (N = 12), 28.1 -> 27.3 (N = 28),
+               39.3 -> 38.4 (N = 50); means unchanged or slightly lower */
             if (x_zero_after > 0 && n_first_ok >= x_zero_after) reg = 0.0;
         }
         if (!use_gn && indef_strategy == 1) hmax_prev = hmax;
@@ -623,6 +626,8 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
             if (chol(K, n) == 0) {
                 if (!use_gn && reg > 0.0) dw_last = reg;
                 if (!use_gn) { dw_spec = reg; n_first_ok = attempt == 0 ? n_first_ok + 1 : 0; }
+                /* experiment KMPC_X_LEAVE: an unshifted exact factorisation succeeded in shift mode -> the region is convex again: leave shift mode */
+                if (x_leave && !use_gn && indef_cfg == 2 && indef_strategy == 1 && reg == 0.0 && attempt == 0) { indef_strategy = 0; n_fail = 0; }
                 reg_final = use_gn ? 0.0 : reg / fmax(hmax, 1e-300);
                 break;
             }
