@@ -449,7 +449,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
        one problem in six its last iteration -- mean 7.90 -> 7.77 at N = 20 -- with cost errors still <= 3.5e-8, but on flat problems the first
        input then moves by up to 5e-5 between two implementations that stop one iteration apart: kept at 1e-7, round 3) */
     const double gap_tol = 1e-7;
-    const int max_polish = 1;
+    const int max_polish = getenv("KMPC_X_POLISH") ? atoi(getenv("KMPC_X_POLISH")) : 1;
     int gn_hold = 0;
     double dw_last = 0.0, dw_spec = 0.0, hmax_prev = 0.0, reg_final = 0.0;
     /* Tuned on the pooled worst-of-4096 statistics of 48 seeded batches (the kernels carry the same values):
