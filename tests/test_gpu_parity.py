@@ -434,3 +434,20 @@ def test_warm_start_from_a_wrong_point_stays_robust():
     assert it.mean() < ci + 5.0, (it.max(), it.mean(), ci)   # (status 0 everywhere already says: inside the iteration cap; the slowest of the 32768 takes ~120)
     rel = (torch.abs(w["cost"] - cc) / torch.clamp(torch.abs(cc), min=1.0)).cpu().numpy()
     assert (rel > 1e-6).mean() < 1e-3
+
+
+@pytest.mark.parametrize("N,cfg,B,dtype", [(20, 2, 65536, "f64"), (50, 5, 8192, "f64"), (8, 2, 65536, "f64"), (20, 3, 65536, "f32"), (28, 2, 32768, "f64"), (40, 5, 8192, "f64")])
+def test_further_seeded_draws_are_all_optimal(N, cfg, B, dtype):
+    """Changes to the iteration's rules (round 3: step acceptance, barrier floor, inertia strategy) are tuned on pooled statistics; what they must never do
+    is lose a problem.  Four further seeded draws per kernel family beyond the bench / certification draws: every problem Optimal, no solve near the cap."""
+    import torch
+    from mkz_mpc_path_follower_amd import BatchMPC
+    tdt, ndt = (torch.float64, np.float64) if dtype == "f64" else (torch.float32, np.float32)
+    s = BatchMPC(N=N, dtype=tdt)
+    for k in range(1, 5):
+        d = make_batch(B, N, cfg_id=cfg, seed=977 * k + N, dtype=ndt)
+        o = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"])
+        torch.cuda.synchronize()
+        st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
+        assert (st == 0).all(), (k, np.bincount(st))
+        assert it.max() <= 120, (k, it.max())
