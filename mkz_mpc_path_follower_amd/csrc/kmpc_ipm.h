@@ -11,7 +11,9 @@
 //     correction and line search.  The CPU checker (test infrastructure, never linked here) states the same algorithm in scalar C.
 //
 // What a back-end SV supplies (all wave-/workgroup-uniform decisions are taken here on values that are identical in every thread):
-//   types / constants  real, N_, n, R, nf, NTH (threads per problem), NF (forms per thread), SROWS, GS (stride of the G_N table), LSTR, MODEL_ID
+//   types / constants  real, N_, n, R, nf, NTH (threads per problem), NF (forms per thread), SROWS, GS (stride of the G_N table), LSTR, MODEL_ID,
+//                      MSPLIT (stage at which the adjoint condensing recursion is split, 0 = not split); with MSPLIT > 0 also LOW0 (first thread of
+//                      the lower half), GMS (stride of the G_M table) and the LDS buffers gmb [3][GMS], pm(c) [2 MSPLIT] (c = 0..3), hm [2 MSPLIT]
 //   ids                lane (stage index), vid (index of the input / form slot this thread holds), refresh_ids()
 //   LDS pointers       xb, wb, cb, lin, gnb, gb, Lc, cs, pt, cwt, kc
 //   problem data       psi0, v0, vt, rx, ry, rp, up(j); x0, y0, kp0..3 for the Frenet functor
