@@ -78,7 +78,8 @@ typedef struct kmpc_config {
     int32_t mu_strategy;    /* barrier update: 0 = Ipopt's default monotone (Fiacco-McCormick), 1 = Mehrotra predictor-corrector
                                (Ipopt's adaptive family; default) */
     int32_t indef_strategy; /* exact Hessian not positive definite: 0 = Gauss-Newton fallback (held for 2 iterations), 1 = Ipopt-style
-                               delta_w shift of the exact Hessian, 2 = hybrid (0 until the second failure of a solve, 1 from then on);
+                               delta_w shift of the exact Hessian, 2 = hybrid (0 until a failure of the exact factorisation -- the first one on cold starts with N <= 28, the second one on
+                               longer horizons and on warm starts --, 1 from then on);
                                2 is the default */
     int32_t schedule;       /* order in which the problems of a batch start on the GPU: 0 = index order, 1 (default) = longest
                                predicted first (key = |v0 - reference speed| + 0.3 * net heading change of the reference), which
