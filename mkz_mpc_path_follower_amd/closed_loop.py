@@ -28,6 +28,8 @@ class ClosedLoop:
         if self.mpc.dtype != torch.float64 or self.mpc.N != self.N or self.mpc.device != sim.device or sim.device.index is None:
             raise ValueError("ClosedLoop needs a float64 BatchMPC with horizon %d on %s (got %s, N=%d, %s)"
                              % (self.N, sim.device, self.mpc.dtype, self.mpc.N, self.mpc.device))
+        if grt.device != sim.device:
+            raise ValueError("waypoint helper on %s, plant on %s: the loop runs on one device" % (grt.device, sim.device))
         self.track_with_time = track_with_time
         self.des_speed = float(target_vel) if target_vel > 0.0 else 0.0  # mpc_cmd_pub.jl:58-62
         dev = sim.device

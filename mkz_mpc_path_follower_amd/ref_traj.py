@@ -81,8 +81,12 @@ class GPSRefTrajectory:
     def get_waypoints_batch(self, pose, v_target=None, want_closest=False):
         """pose [B,3] (X_init, Y_init, yaw_init), v_target [B] or None -> ref [B,H+1,3] (device), stop [B] int32"""
         pose = torch.as_tensor(pose, dtype=torch.float64, device=self.device).contiguous()
+        if pose.dim() != 2 or pose.shape[1] != 3:
+            raise ValueError("pose: expected [B,3], got %s" % (tuple(pose.shape),))
         B = pose.shape[0]
         vt = None if v_target is None else torch.as_tensor(v_target, dtype=torch.float64, device=self.device).contiguous()
+        if vt is not None and tuple(vt.shape) != (B,):
+            raise ValueError("v_target: expected [%d], got %s" % (B, tuple(vt.shape)))
         ref = torch.empty((B, self.traj_horizon + 1, 3), dtype=torch.float64, device=self.device)
         stop = torch.empty((B,), dtype=torch.int32, device=self.device)
         closest = torch.empty((B,), dtype=torch.int32, device=self.device) if want_closest else None

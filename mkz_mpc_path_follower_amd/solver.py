@@ -181,6 +181,8 @@ def solve_host(N, z0, ref, v_target, u_prev, weights=None, dtype=np.float64, war
     cfg = Config()
     _lib.check(lib.kmpc_config_default(C.byref(cfg), int(N), KMPC_F64 if dtype == np.float64 else KMPC_F32))
     for k, v in options.items():
+        if not hasattr(cfg, k):
+            raise TypeError("unknown option %r" % k)
         setattr(cfg, k, v)
     h = C.c_void_p()
     _lib.check(lib.kmpc_create(C.byref(cfg), device, C.byref(h)))

@@ -41,6 +41,9 @@ class VehicleSimulator:
 
     def _update_vehicle_model(self, n_updates=1):
         """n_updates passes of :58-107 (each 10 Euler sub-steps of 1 ms + the actuator lag :109-113)"""
+        for t, w in ((self.state, 8), (self.cmd, 2)):  # `state` and `cmd` are plain attributes: what reaches the kernel is a raw pointer
+            if not (t.dtype == torch.float64 and tuple(t.shape) == (self.B, w) and t.is_contiguous() and t.device == self.device):
+                raise ValueError("state [B,8] / cmd [B,2] must stay contiguous float64 tensors on %s (write into them with copy_)" % self.device)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         rc = self._lib.kmpc_sim_advance_batch(self.device.index, self.B, C.c_void_p(self.state.data_ptr()),
                                               C.c_void_p(self.cmd.data_ptr()), int(n_updates), stream)
