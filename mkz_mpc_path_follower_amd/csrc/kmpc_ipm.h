@@ -46,7 +46,7 @@ enum { PT_DT = 0, PT_DTC, PT_RR, PT_DT2, PT_DTL, PT_LB, PT_TOL, PT_GAP_TOL, PT_T
        PT_IKRD_NC /* barrier floor relative to the dual infeasibility in shifted (non-convex) iterations */ };
 static_assert(PT_IKRD_NC == 31, "the table has 32 entries");
 // wave-uniform scalars of the solve that are read once or twice per iteration: parked in LDS (cs[]), not in VGPRs
-enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J, C_LGS, C_JP, C_EP1, C_EP2 /* optimality error of the last two iterations */ };
+enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J, C_LGS, C_JP, C_EP1, C_EP2 /* optimality error of the last two iterations */, C_AL /* length of the last accepted step */ };
 
 // sizes every compile-time-horizon solver derives from N (n inputs, R rate forms, nf forms; packed lower triangle of K with the rhs row)
 #define KMPC_HORIZON_CONSTANTS(N)                                                                                              \
@@ -625,12 +625,19 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
     // cancellation once an active slack is ~1e-9
     T sup[NF], slo[NF], isu[NF], isl[NF], lu[NF], ll[NF], aut[NF], w[NF];  // isu/isl = 1/slack, refreshed when the slacks move
     bool fv[NF];
+    // degenerate pairs (slack and multiplier vanish together: Newton halves them per iteration, x0.375 with the corrector): bit 2i / 2i+1 = the upper /
+    // lower side of form i was seen shrinking that way in the last accepted full step; its barrier stiffness lambda/s then enters K (and the recovery of
+    // its multiplier step, consistently) scaled by KMPC_DEGEN_THETA -- the step of a double root.  Set in the acceptance block below.
+    unsigned dg = 0;
+    const T theta = (T)KMPC_DEGEN_THETA;
+#define DG_U(i) ((dg >> (2 * (i))) & 1u ? theta : (T)1)
+#define DG_L(i) ((dg >> (2 * (i) + 1)) & 1u ? theta : (T)1)
 #pragma unroll
     for (int i = 0; i < NF; ++i) { const int f = s.vid + NTH * i; fv[i] = f < nf; lu[i] = ll[i] = sup[i] = slo[i] = isu[i] = isl[i] = aut[i] = (T)0; }
     int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0, n_first_ok = 0;
     T *cs = s.cs;
     cs[C_ERR] = (T)1e30; cs[C_RDS] = 0; cs[C_DWL] = 0; cs[C_DWS] = 0; cs[C_HMAX] = 0; cs[C_MUF] = 0; cs[C_PHI0] = 0; cs[C_DPHI] = 0;
-    cs[C_AD] = 0; cs[C_J] = 0; cs[C_LGS] = 0; cs[C_JP] = (T)1e30; cs[C_EP1] = (T)1e30; cs[C_EP2] = (T)1e30;
+    cs[C_AD] = 0; cs[C_J] = 0; cs[C_LGS] = 0; cs[C_JP] = (T)1e30; cs[C_EP1] = (T)1e30; cs[C_EP2] = (T)1e30; cs[C_AL] = (T)1;
     int indef = indef_cfg == 2 ? 0 : indef_cfg, n_fail = 0;  // 2 = hybrid: GN fallback, delta_w shift from the 2nd failure on
     bool have_best = false;
     T mu = warm ? s.pt[PT_WARM_MU] : s.pt[PT_MU_INIT], sc = 1, Jt = 0, alpha = 0, reg = 0;
@@ -758,13 +765,22 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
             // accepted: dual step from the pre-step slacks, then the slacks advance with the step
             cs[C_LGS] = slg;  // = sum log(slack) of the new iterate: the next barrier value re-uses it
             const T ad = cs[C_AD];
+            cs[C_AL] = alpha;
+            const bool full_step = alpha >= (T)0.9 && ad >= (T)0.9;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 const T su = sup[i], sl = slo[i];
-                lu[i] += ad * ((mu - s.cu(i) - lu[i] * su) * isu[i] + lu[i] * isu[i] * aut[i]);
-                ll[i] += ad * ((mu - s.cl(i) - ll[i] * sl) * isl[i] - ll[i] * isl[i] * aut[i]);
+                const T lu0 = lu[i], ll0 = ll[i];
+                lu[i] += ad * ((mu - s.cu(i) - lu0 * su) * isu[i] + DG_U(i) * lu0 * isu[i] * aut[i]);
+                ll[i] += ad * ((mu - s.cl(i) - ll0 * sl) * isl[i] - DG_L(i) * ll0 * isl[i] * aut[i]);
                 sup[i] = su - alpha * aut[i];
                 slo[i] = sl + alpha * aut[i];
+                // the signature of a degenerate pair: a (nearly) full step took the same share off the slack and off its multiplier, on a side that is
+                // close to its bound and well above the barrier target
+                const T wid5 = (T)0.05 * (su + sl), mu10 = (T)10 * mu;
+                const bool du_ = full_step && sup[i] < (T)0.7 * su && lu[i] < (T)0.7 * lu0 && fabs(sup[i] * isu[i] * lu0 - lu[i]) < (T)0.2 * lu0 && su * lu0 > mu10 && su < wid5;
+                const bool dl_ = full_step && slo[i] < (T)0.7 * sl && ll[i] < (T)0.7 * ll0 && fabs(slo[i] * isl[i] * ll0 - ll[i]) < (T)0.2 * ll0 && sl * ll0 > mu10 && sl < wid5;
+                dg = (dg & ~(3u << (2 * i))) | ((du_ ? 1u : 0u) << (2 * i)) | ((dl_ ? 1u : 0u) << (2 * i + 1));
                 isu[i] = fv[i] ? rcp_(sup[i]) : (T)0; isl[i] = fv[i] ? rcp_(slo[i]) : (T)0;
             }
         }
@@ -876,7 +892,7 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
             }
             // K = sc*H + A^T Sigma A with the affine right-hand side -sc*g riding along
 #pragma unroll
-            for (int i = 0; i < NF; ++i) w[i] = lu[i] * isu[i] + ll[i] * isl[i];
+            for (int i = 0; i < NF; ++i) w[i] = DG_U(i) * lu[i] * isu[i] + DG_L(i) * ll[i] * isl[i];
             s.stage_form_weights(w);
             STAMP_AT(s, 6);
             const bool factored = s.kkt_factor(sc, reg, use_exact && indef == 1 && first_attempt);
@@ -921,7 +937,7 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 for (int i = 0; i < NF; ++i) {
                     const T qu = aut[i] * isu[i], ql = aut[i] * isl[i];  // -ds_u/s_u, ds_l/s_l
                     mx[0] = fmax(mx[0], fmax(qu, -ql));
-                    mx[1] = fmax(mx[1], fmax((T)1 - qu, (T)1 + ql));
+                    mx[1] = fmax(mx[1], fmax((T)1 - DG_U(i) * qu, (T)1 + DG_L(i) * ql));
                     sm[0] += sup[i] * lu[i] + slo[i] * ll[i];
                 }
                 s.template reduce<1, 2>(sm, mx);
@@ -930,7 +946,7 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
 #pragma unroll
                 for (int i = 0; i < NF; ++i) {
                     const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
-                    const T dlu = -lu[i] - lu[i] * isu[i] * dsu, dll = -ll[i] - ll[i] * isl[i] * dsl;
+                    const T dlu = -lu[i] - DG_U(i) * lu[i] * isu[i] * dsu, dll = -ll[i] - DG_L(i) * ll[i] * isl[i] * dsl;
                     sa[0] += (su + apa * dsu) * (lu[i] + ada * dlu) + (sl + apa * dsl) * (ll[i] + ada * dll);
                     s.cu(i) = dsu * dlu; s.cl(i) = dsl * dll;
                 }
@@ -947,8 +963,13 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 // N = 8; worst-of-4096 statistics unchanged).  With no floor at all outside shift mode a rare problem cycles to the iteration cap.
                 const bool shifted = use_exact && reg > (T)0;
                 const bool converging = cs[C_ERR] < cs[C_EP1] && cs[C_EP1] < cs[C_EP2];
-                const T floor_k = shifted ? s.pt[PT_IKRD_NC] : ((indef == 1 || !converging) ? (T)KMPC_IKRD : (T)0);
-                mu = fmax(mu, fmin(mucur, cs[C_RDS] * floor_k));
+                // ... and after a tiny fraction-to-the-boundary step (alpha < KMPC_UNSTICK) the floor applies without its cap at the current mean complementarity:
+                // a warm start from a wrong point begins with mu = 1e-7 and slacks 1e-5 off the bounds -- mu_cur can then never grow, the Newton direction
+                // keeps pointing into the bound and the solve crawls to the iteration cap in steps of 1e-6 (1 of 32 768 wrong-point warm starts at N = 8 and
+                // at N = 20, tools/warm_probe.py; with the rule: at most 20 / 34 iterations; warm starts from the own solution and cold starts unchanged)
+                const bool stuck = cs[C_AL] < (T)KMPC_UNSTICK;
+                const T floor_k = shifted ? s.pt[PT_IKRD_NC] : ((stuck || indef == 1 || !converging) ? (T)KMPC_IKRD : (T)0);
+                mu = fmax(mu, fmin(stuck ? (T)1e30 : mucur, cs[C_RDS] * floor_k));
                 corr_active = true;
                 STAMP_AT(s, 7);
             }
@@ -976,8 +997,8 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
             for (int i = 0; i < NF; ++i)
                 if (fv[i]) {
                     const T su = sup[i], sl = slo[i], dsu = -aut[i], dsl = aut[i];
-                    const T dlu = (mu - s.cu(i) - lu[i] * su) * isu[i] - lu[i] * isu[i] * dsu;
-                    const T dll = (mu - s.cl(i) - ll[i] * sl) * isl[i] - ll[i] * isl[i] * dsl;
+                    const T dlu = (mu - s.cu(i) - lu[i] * su) * isu[i] - DG_U(i) * lu[i] * isu[i] * dsu;
+                    const T dll = (mu - s.cl(i) - ll[i] * sl) * isl[i] - DG_L(i) * ll[i] * isl[i] * dsl;
                     sm[0] += mu * (isu[i] - isl[i]) * aut[i];
                     mx[0] = fmax(mx[0], fmax(-dsu * isu[i], -dsl * isl[i]));
                     mx[1] = fmax(mx[1], fmax(-dlu * rcp_(lu[i]), -dll * rcp_(ll[i])));

@@ -414,15 +414,17 @@ def test_barrier_floor_gate_keeps_the_cycling_problem(oracle):
     assert r["status"][0] == 0 and r["iters"][0] <= 20 and abs(r["cost"][0] - 802.0932995) < 1e-5, (r["status"], r["iters"], r["cost"])
 
 
-def test_warm_start_from_a_wrong_point_stays_robust():
+@pytest.mark.parametrize("N,warm_mu", [(20, 1e-6), (20, 1e-7), (8, 1e-7)])
+def test_warm_start_from_a_wrong_point_stays_robust(N, warm_mu):
     """A warm start may be arbitrarily poor (here: the solution of an unrelated problem).  Every problem must still end Optimal, well inside the iteration cap,
     at the cold solve's cost or in another local minimum of the non-convex program (< 0.1 %).  Round 3: switching the hybrid inertia strategy to shift mode at the
-    FIRST failed factorisation -- right for cold starts -- made 3 of these 32768 warm starts hit the cap (they begin at mu = 1e-6); warm starts keep the two-failure rule."""
+    FIRST failed factorisation -- right for cold starts -- made 3 of these 32768 warm starts hit the cap (they begin at mu = 1e-6); warm starts keep the two-failure rule.
+    With warm_mu = 1e-7 (default 1e-6) one problem at N = 8 and one at N = 20 crawled to the cap in 1e-6 steps until the barrier floor lost its cap after a tiny step."""
     import torch
     from mkz_mpc_path_follower_amd import BatchMPC
-    N, B = 20, 32768
+    B = 32768
     a, b = make_batch(B, N, cfg_id=5), make_batch(B, N, cfg_id=6)
-    s = BatchMPC(N=N)
+    s = BatchMPC(N=N, warm_mu=warm_mu)
     oa = s.solve(a["z0"], a["ref"], a["v_target"], a["u_prev"], want_U=True)
     wu = oa["U"].clone()
     cold = s.solve(b["z0"], b["ref"], b["v_target"], b["u_prev"])
@@ -431,7 +433,7 @@ def test_warm_start_from_a_wrong_point_stays_robust():
     torch.cuda.synchronize()
     st, it = w["status"].cpu().numpy(), w["iters"].cpu().numpy()
     assert (st == 0).all(), np.bincount(st)
-    assert it.mean() < ci + 5.0, (it.max(), it.mean(), ci)   # (status 0 everywhere already says: inside the iteration cap; the slowest of the 32768 takes ~120)
+    assert it.mean() < ci + 5.0 and it.max() <= 150, (it.max(), it.mean(), ci)   # (the slowest of the 32768 takes ~120 at warm_mu = 1e-6)
     rel = (torch.abs(w["cost"] - cc) / torch.clamp(torch.abs(cc), min=1.0)).cpu().numpy()
     assert (rel > 1e-6).mean() < 1e-3
 

@@ -224,3 +224,41 @@ def test_barrier_floor_gate_keeps_the_cycling_problem(oracle):
     b = 1010
     r = O.solve_condensed_batch(O.params(50), d["z0"][b:b + 1], d["ref"][b:b + 1], d["v_target"][b:b + 1], d["u_prev"][b:b + 1], nthreads=1)
     assert r["status"][0] == 0 and r["iters"][0] <= 20 and abs(r["cost"][0] - 802.0932995) < 1e-5, (r["status"], r["iters"], r["cost"])
+
+
+def test_degenerate_pair_rule_shortens_the_end_game(oracle, monkeypatch):
+    """Round 3: a standing start whose optimum accelerates at the limit to the end of the horizon -- the bound of the last acceleration input is active with a zero
+    multiplier (only the rate cost ties a_{N-1} to a_{N-2}), slack and multiplier vanish together and Newton's method shrinks them x0.375 per iteration.  With the
+    pair's barrier stiffness scaled by theta = 0.6 once it is seen shrinking that way: 16 iterations instead of 19, same cost."""
+    from mkz_mpc_path_follower_amd.synthetic import make_batch
+    O = oracle
+    d = make_batch(4096, 20, cfg_id=2)
+    b = 3694
+    args = (O.params(20), d["z0"][b:b + 1], d["ref"][b:b + 1], d["v_target"][b:b + 1], d["u_prev"][b:b + 1])
+    r = O.solve_condensed_batch(*args, nthreads=1)
+    monkeypatch.setenv("KMPC_X_DEGEN", "1")
+    r0 = O.solve_condensed_batch(*args, nthreads=1)
+    assert r["status"][0] == 0 and r0["status"][0] == 0 and r["iters"][0] <= r0["iters"][0] - 2, (r["iters"], r0["iters"])
+    assert abs(r["cost"][0] - r0["cost"][0]) <= 1e-8 * abs(r0["cost"][0])
+    assert np.abs(r["U"][0, 1:, 0] - 1.0).max() <= 1e-4  # the whole horizon at a_max (but the rate-limited first step)
+
+
+def test_wrong_point_warm_start_with_a_tiny_barrier_does_not_crawl(oracle, monkeypatch):
+    """Round 3: warm start from the solution of an unrelated problem with warm_mu = 1e-7 (not the default 1e-6): slacks 1e-5 off the bounds, mu_cur ~ 3e-5 and a
+    dual infeasibility of 100 -- every step is a 1e-6 fraction-to-the-boundary step and mu, capped at mu_cur, can never grow: 200 iterations without the rule
+    that lifts the cap after a tiny step."""
+    from mkz_mpc_path_follower_amd.synthetic import make_batch
+    O = oracle
+    N, B, i = 8, 32768, 2310
+    a, b = make_batch(B, N, cfg_id=5), make_batch(B, N, cfg_id=6)
+    p = O.params(N)
+    ra = O.solve_condensed_batch(p, a["z0"][i:i + 1], a["ref"][i:i + 1], a["v_target"][i:i + 1], a["u_prev"][i:i + 1], nthreads=1)
+    o = O.opts()
+    o.warm, o.warm_mu, o.warm_push = 1, 1e-7, 1e-5
+    args = (p, b["z0"][i:i + 1], b["ref"][i:i + 1], b["v_target"][i:i + 1], b["u_prev"][i:i + 1])
+    rw = O.solve_condensed_batch(*args, o=o, U0=ra["U"].reshape(1, -1), nthreads=1)
+    rc = O.solve_condensed_batch(*args, nthreads=1)
+    assert rw["status"][0] == 0 and rw["iters"][0] <= 25 and abs(rw["cost"][0] - rc["cost"][0]) <= 1e-6 * max(1.0, abs(rc["cost"][0])), (rw["status"], rw["iters"])
+    monkeypatch.setenv("KMPC_X_UNSTICK", "0")
+    r0 = O.solve_condensed_batch(*args, o=o, U0=ra["U"].reshape(1, -1), nthreads=1)
+    assert r0["status"][0] == 1 and r0["iters"][0] == o.max_iter, (r0["status"], r0["iters"])
