@@ -34,7 +34,7 @@
 // shrinking that way enters the KKT matrix with theta * lambda/s (theta < 1 lengthens its step: s+ = 0.13 s at theta = 0.6; below 0.45 the corrected
 // step overshoots the bound and the fraction-to-the-boundary rule cuts EVERY component).  K stays positive definite and the right-hand side is the
 // barrier gradient, so the direction is a descent direction of phi_mu as before.  CPU port, 12 x 4096 seeded problems at N = 20: mean iterations 7.45 ->
-// 7.18, E[worst of 4096] 21.7 -> 19.4; same minima (costs agree to 2e-8).  0.75: 20.1; 0.5: 19.4; 0.4: 25.6.
+// 7.10, E[worst of 4096] 21.7 -> 19.6; same minima (costs agree to 2e-8).  0.75: 20.1; 0.5: 19.4; 0.4: 25.6.
 // barrier floor without its mu_cur cap after an accepted step shorter than this (kmpc_ipm.h, the Mehrotra barrier update): un-sticks warm starts from a wrong point
 #ifndef KMPC_UNSTICK
 #define KMPC_UNSTICK 1e-4

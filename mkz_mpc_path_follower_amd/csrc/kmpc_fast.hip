@@ -736,9 +736,10 @@ static hipError_t launch_fast_n(const KP &P, const KIO<T> &io, hipStream_t st)
 }
 
 // Frenet-frame functor (kmpc_config.model = 1): io.ref carries k_poly [B,4]  (fp64 at N = 28: 34.5 KB of LDS per wave leave one wave per
-// SIMD anyway, so the bound says so and the allocator may use all 512 registers)
+// SIMD anyway, so the bound says so and the allocator may use all 512 registers; fp64 at N = 8 ran at three waves per SIMD with 42 spilled registers
+// until the degenerate-pair rule moved one of the spill stores into a divergent region -- tools/spill_exec_check.py -- two waves, no scratch)
 template <typename T, int N>
-__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N >= 28 ? 1 : (N <= 8 ? 3 : 2)) : (N <= 20 ? 4 : (N >= 28 ? 2 : 3))) void kmpc_solve_fast_frenet_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? (N >= 28 ? 1 : 2) : (N <= 20 ? 4 : (N >= 28 ? 2 : 3))) void kmpc_solve_fast_frenet_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FastSolver<T, N, 1>::lds_elems() * sizeof(T)];
     ipm::run_solver<FastSolver<T, N, 1>>(P, io, smem);

@@ -625,13 +625,12 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
     // cancellation once an active slack is ~1e-9
     T sup[NF], slo[NF], isu[NF], isl[NF], lu[NF], ll[NF], aut[NF], w[NF];  // isu/isl = 1/slack, refreshed when the slacks move
     bool fv[NF];
-    // degenerate pairs (slack and multiplier vanish together: Newton halves them per iteration, x0.375 with the corrector): bit 2i / 2i+1 = the upper /
-    // lower side of form i was seen shrinking that way in the last accepted full step; its barrier stiffness lambda/s then enters K (and the recovery of
-    // its multiplier step, consistently) scaled by KMPC_DEGEN_THETA -- the step of a double root.  Set in the acceptance block below.
-    unsigned dg = 0;
-    const T theta = (T)KMPC_DEGEN_THETA;
-#define DG_U(i) ((dg >> (2 * (i))) & 1u ? theta : (T)1)
-#define DG_L(i) ((dg >> (2 * (i) + 1)) & 1u ? theta : (T)1)
+    // degenerate pairs (slack and multiplier vanish together: Newton halves them per iteration, x0.375 with the corrector): a side of a form that was seen
+    // shrinking that way in the last accepted full step enters K (and the recovery of its multiplier step, consistently) with its barrier stiffness lambda/s
+    // scaled by KMPC_DEGEN_THETA -- the step of a double root.  The mark is the lowest mantissa bit of the side's reciprocal slack (isu / isl are refreshed
+    // exactly where the mark is decided, in the acceptance block below; one ulp of a Newton-refined reciprocal): no register, no LDS.
+#define DG_U(i) (lsb_get(isu[i]) ? (T)KMPC_DEGEN_THETA : (T)1)
+#define DG_L(i) (lsb_get(isl[i]) ? (T)KMPC_DEGEN_THETA : (T)1)
 #pragma unroll
     for (int i = 0; i < NF; ++i) { const int f = s.vid + NTH * i; fv[i] = f < nf; lu[i] = ll[i] = sup[i] = slo[i] = isu[i] = isl[i] = aut[i] = (T)0; }
     int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0, n_first_ok = 0;
@@ -775,13 +774,10 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 ll[i] += ad * ((mu - s.cl(i) - ll0 * sl) * isl[i] - DG_L(i) * ll0 * isl[i] * aut[i]);
                 sup[i] = su - alpha * aut[i];
                 slo[i] = sl + alpha * aut[i];
-                // the signature of a degenerate pair: a (nearly) full step took the same share off the slack and off its multiplier, on a side that is
-                // close to its bound and well above the barrier target
-                const T wid5 = (T)0.05 * (su + sl), mu10 = (T)10 * mu;
-                const bool du_ = full_step && sup[i] < (T)0.7 * su && lu[i] < (T)0.7 * lu0 && fabs(sup[i] * isu[i] * lu0 - lu[i]) < (T)0.2 * lu0 && su * lu0 > mu10 && su < wid5;
-                const bool dl_ = full_step && slo[i] < (T)0.7 * sl && ll[i] < (T)0.7 * ll0 && fabs(slo[i] * isl[i] * ll0 - ll[i]) < (T)0.2 * ll0 && sl * ll0 > mu10 && sl < wid5;
-                dg = (dg & ~(3u << (2 * i))) | ((du_ ? 1u : 0u) << (2 * i)) | ((dl_ ? 1u : 0u) << (2 * i + 1));
-                isu[i] = fv[i] ? rcp_(sup[i]) : (T)0; isl[i] = fv[i] ? rcp_(slo[i]) : (T)0;
+                // the signature of a degenerate pair: a (nearly) full step took the same share off the slack and off its multiplier
+                const bool du_ = full_step && sup[i] < (T)0.7 * su && lu[i] < (T)0.7 * lu0 && fabs(sup[i] * isu[i] * lu0 - lu[i]) < (T)0.2 * lu0;
+                const bool dl_ = full_step && slo[i] < (T)0.7 * sl && ll[i] < (T)0.7 * ll0 && fabs(slo[i] * isl[i] * ll0 - ll[i]) < (T)0.2 * ll0;
+                isu[i] = fv[i] ? lsb_set(rcp_(sup[i]), du_) : (T)0; isl[i] = fv[i] ? lsb_set(rcp_(slo[i]), dl_) : (T)0;
             }
         }
         const bool restep = mode == RESTEP;
@@ -800,7 +796,7 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                         T bu_, bl_;
                         s.form_bounds(s.vid + NTH * i, bu_, bl_);
                         sup[i] = bu_ - w[i]; slo[i] = bl_ + w[i];
-                        isu[i] = fv[i] ? (T)1 / sup[i] : (T)0; isl[i] = fv[i] ? (T)1 / slo[i] : (T)0;
+                        isu[i] = fv[i] ? lsb_set((T)1 / sup[i], false) : (T)0; isl[i] = fv[i] ? lsb_set((T)1 / slo[i], false) : (T)0;
                     }
                     T sm[1] = {(T)0}, mx[1] = {(T)0};
 #pragma unroll

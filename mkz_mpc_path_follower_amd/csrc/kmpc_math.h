@@ -13,6 +13,11 @@ DEV double rsqrt_(double d) {
     return y;
 }
 // reciprocal without the IEEE division's scaling / fix-up sequence (operands here are well inside the normal range): ~1 ulp
+// lowest mantissa bit as a one-bit mark on a positive value whose last ulp carries no information (kmpc_ipm.h: degenerate-pair mark on 1/slack)
+DEV bool lsb_get(double x) { return (__double2loint(x) & 1) != 0; }
+DEV bool lsb_get(float x) { return (__float_as_int(x) & 1) != 0; }
+DEV double lsb_set(double x, bool f) { return __hiloint2double(__double2hiint(x), (__double2loint(x) & ~1) | (f ? 1 : 0)); }
+DEV float lsb_set(float x, bool f) { return __int_as_float((__float_as_int(x) & ~1) | (f ? 1 : 0)); }
 DEV double rcp_(double d) {
     double y = __builtin_amdgcn_rcp(d);
     double e = fma(-d, y, 1.0);

@@ -460,7 +460,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
     /* degenerate complementarity pairs (slack and multiplier vanish together; structurally the last acceleration input, tied to its neighbour by the
        rate cost only): Newton halves both per iteration (x0.375 with the corrector).  A side seen shrinking that way in an accepted (nearly) full step
        enters K -- and the recovery of its multiplier step -- with theta * lambda/s: the step of a double root (s+ = 0.13 s at theta = 0.6; below 0.45
-       the corrected step overshoots the bound).  12 x 4096 seeded problems, N = 20: mean iterations 7.45 -> 7.18, E[worst of 4096] 21.7 -> 19.4;
+       the corrected step overshoots the bound).  12 x 4096 seeded problems, N = 20: mean iterations 7.45 -> 7.10, E[worst of 4096] 21.7 -> 19.6;
        N = 8: 6.48 -> 6.13 / 13.5 -> 11.4; N = 12: 8.56 -> 7.76; N = 28: 7.70 -> 7.53; N = 50: 8.97 -> 8.84; same minima (costs to 2e-8).
        KMPC_X_DEGEN = 1 switches it off. */
     const double x_degen = getenv("KMPC_X_DEGEN") ? atof(getenv("KMPC_X_DEGEN")) : 0.6;
@@ -761,11 +761,12 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
         memcpy(U, Ut, (size_t)n * sizeof(double));
         if (n_tiny >= 2) { status = err0 <= 1e3 * o->tol ? KMPC_OPTIMAL : KMPC_NUMERICAL_ERROR; tiny_stop = 1; break; }
         if (x_degen > 0.0 && x_degen < 1.0) for (int f = 0; f < nf; ++f) {
-            const double wid = su[f] + sl[f];
+            /* the signature: an accepted (nearly) full step took the same share off the slack and off its multiplier.  (Also requiring the side to be near its
+               bound or its product well above mu changes nothing or costs iterations: 7.18 against 7.10 mean at N = 20) */
             const double rsu = (su[f] - alpha * aut[f]) / su[f], rlu = (lu[f] + ad * dlu[f]) / lu[f];
             const double rsl = (sl[f] + alpha * aut[f]) / sl[f], rll = (ll[f] + ad * dll[f]) / ll[f];
-            thu[f] = (alpha >= 0.9 && ad >= 0.9 && rsu < 0.7 && rlu < 0.7 && fabs(rsu - rlu) < 0.2 && su[f] * lu[f] > 10.0 * mu && su[f] < 0.05 * wid) ? x_degen : 1.0;
-            thl[f] = (alpha >= 0.9 && ad >= 0.9 && rsl < 0.7 && rll < 0.7 && fabs(rsl - rll) < 0.2 && sl[f] * ll[f] > 10.0 * mu && sl[f] < 0.05 * wid) ? x_degen : 1.0;
+            thu[f] = (alpha >= 0.9 && ad >= 0.9 && rsu < 0.7 && rlu < 0.7 && fabs(rsu - rlu) < 0.2) ? x_degen : 1.0;
+            thl[f] = (alpha >= 0.9 && ad >= 0.9 && rsl < 0.7 && rll < 0.7 && fabs(rsl - rll) < 0.2) ? x_degen : 1.0;
         }
         for (int f = 0; f < nf; ++f) {
             su[f] -= alpha * aut[f];
