@@ -629,8 +629,13 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
     // shrinking that way in the last accepted full step enters K (and the recovery of its multiplier step, consistently) with its barrier stiffness lambda/s
     // scaled by KMPC_DEGEN_THETA -- the step of a double root.  The mark is the lowest mantissa bit of the side's reciprocal slack (isu / isl are refreshed
     // exactly where the mark is decided, in the acceptance block below; one ulp of a Newton-refined reciprocal): no register, no LDS.
-#define DG_U(i) (lsb_get(isu[i]) ? (T)KMPC_DEGEN_THETA : (T)1)
-#define DG_L(i) (lsb_get(isl[i]) ? (T)KMPC_DEGEN_THETA : (T)1)
+    // (theta is re-derived from the bit at every use -- an integer AND, a conversion and an fma behind an opaque barrier: left to itself the compiler keeps the
+    // 2 NF selected factors in registers across the iteration, which the kernels at their register limit pay with 40 more spilled registers)
+    // fp64 only: the fp32 solves end at their rounding floor (error ~1e-4) before a degenerate pair's tail begins -- measured: no iteration saved, 2.5 % of
+    // the launch spent on the marks -- so the fp32 instantiations compile the rule out
+    constexpr bool DGR = sizeof(T) == 8;
+#define DG_U(i) (DGR ? dg_theta(isu[i]) : (T)1)
+#define DG_L(i) (DGR ? dg_theta(isl[i]) : (T)1)
 #pragma unroll
     for (int i = 0; i < NF; ++i) { const int f = s.vid + NTH * i; fv[i] = f < nf; lu[i] = ll[i] = sup[i] = slo[i] = isu[i] = isl[i] = aut[i] = (T)0; }
     int status = 1, iters = 0, ls = 0, attempt = 0, n_polish = 0, n_accept = 0, gn_hold = 0, n_first_ok = 0;
@@ -769,15 +774,13 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 const T su = sup[i], sl = slo[i];
-                const T lu0 = lu[i], ll0 = ll[i];
-                lu[i] += ad * ((mu - s.cu(i) - lu0 * su) * isu[i] + DG_U(i) * lu0 * isu[i] * aut[i]);
-                ll[i] += ad * ((mu - s.cl(i) - ll0 * sl) * isl[i] - DG_L(i) * ll0 * isl[i] * aut[i]);
+                lu[i] += ad * ((mu - s.cu(i) - lu[i] * su) * isu[i] + DG_U(i) * lu[i] * isu[i] * aut[i]);
+                ll[i] += ad * ((mu - s.cl(i) - ll[i] * sl) * isl[i] - DG_L(i) * ll[i] * isl[i] * aut[i]);
                 sup[i] = su - alpha * aut[i];
                 slo[i] = sl + alpha * aut[i];
-                // the signature of a degenerate pair: a (nearly) full step took the same share off the slack and off its multiplier
-                const bool du_ = full_step && sup[i] < (T)0.7 * su && lu[i] < (T)0.7 * lu0 && fabs(sup[i] * isu[i] * lu0 - lu[i]) < (T)0.2 * lu0;
-                const bool dl_ = full_step && slo[i] < (T)0.7 * sl && ll[i] < (T)0.7 * ll0 && fabs(slo[i] * isl[i] * ll0 - ll[i]) < (T)0.2 * ll0;
-                isu[i] = fv[i] ? lsb_set(rcp_(sup[i]), du_) : (T)0; isl[i] = fv[i] ? lsb_set(rcp_(slo[i]), dl_) : (T)0;
+                // a candidate (marked where the step was computed) becomes a degenerate pair when the step was accepted (nearly) in full
+                const int cb = DGR && full_step ? lsb2_get(aut[i]) : 0;
+                isu[i] = fv[i] ? lsb_set(rcp_(sup[i]), (cb & 1) != 0) : (T)0; isl[i] = fv[i] ? lsb_set(rcp_(slo[i]), (cb & 2) != 0) : (T)0;
             }
         }
         const bool restep = mode == RESTEP;
@@ -996,8 +999,14 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                     const T dlu = (mu - s.cu(i) - lu[i] * su) * isu[i] - DG_U(i) * lu[i] * isu[i] * dsu;
                     const T dll = (mu - s.cl(i) - ll[i] * sl) * isl[i] - DG_L(i) * ll[i] * isl[i] * dsl;
                     sm[0] += mu * (isu[i] - isl[i]) * aut[i];
-                    mx[0] = fmax(mx[0], fmax(-dsu * isu[i], -dsl * isl[i]));
-                    mx[1] = fmax(mx[1], fmax(-dlu * rcp_(lu[i]), -dll * rcp_(ll[i])));
+                    // shares of the slack and of its multiplier that the full step takes off (the step lengths' inputs) -- and the signature of a degenerate
+                    // pair: both above 0.3 and within 0.2 of each other.  The two candidate marks ride in the two lowest mantissa bits of a_f^T du until
+                    // the step is accepted (no register)
+                    const T qsu = -dsu * isu[i], qsl = -dsl * isl[i], qlu = -dlu * rcp_(lu[i]), qll = -dll * rcp_(ll[i]);
+                    mx[0] = fmax(mx[0], fmax(qsu, qsl));
+                    mx[1] = fmax(mx[1], fmax(qlu, qll));
+                    const bool cu_ = qsu > (T)0.3 && qlu > (T)0.3 && fabs(qsu - qlu) < (T)0.2, cl_ = qsl > (T)0.3 && qll > (T)0.3 && fabs(qsl - qll) < (T)0.2;
+                    if (DGR) aut[i] = lsb2_set(aut[i], (cu_ ? 1 : 0) | (cl_ ? 2 : 0));
                 }
             s.template reduce<1, 2>(sm, mx);
             // fraction to the boundary: alpha = min(1, tau * min(-s/ds)) = tau / max(tau, max(-ds/s))

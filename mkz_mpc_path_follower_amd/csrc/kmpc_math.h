@@ -18,6 +18,17 @@ DEV bool lsb_get(double x) { return (__double2loint(x) & 1) != 0; }
 DEV bool lsb_get(float x) { return (__float_as_int(x) & 1) != 0; }
 DEV double lsb_set(double x, bool f) { return __hiloint2double(__double2hiint(x), (__double2loint(x) & ~1) | (f ? 1 : 0)); }
 DEV float lsb_set(float x, bool f) { return __int_as_float((__float_as_int(x) & ~1) | (f ? 1 : 0)); }
+// 1 or KMPC_DEGEN_THETA by the mark in the lowest mantissa bit, recomputed at every call (the empty asm keeps the result from being shared between calls)
+template <typename T> DEV T dg_theta(T r)
+{
+    int b = lsb_get(r) ? 1 : 0;
+    asm volatile("" : "+v"(b));
+    return (T)1 - (T)(1.0 - KMPC_DEGEN_THETA) * (T)b;
+}
+DEV int lsb2_get(double x) { return __double2loint(x) & 3; }
+DEV int lsb2_get(float x) { return __float_as_int(x) & 3; }
+DEV double lsb2_set(double x, int b) { return __hiloint2double(__double2hiint(x), (__double2loint(x) & ~3) | b); }
+DEV float lsb2_set(float x, int b) { return __int_as_float((__float_as_int(x) & ~3) | b); }
 DEV double rcp_(double d) {
     double y = __builtin_amdgcn_rcp(d);
     double e = fma(-d, y, 1.0);

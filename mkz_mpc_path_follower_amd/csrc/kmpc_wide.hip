@@ -449,10 +449,9 @@ template <typename T, int N> struct WideSolver {
 // Workgroups per CU.  The workgroup is latency-bound between its barriers and the SIMDs' issue ports are mostly idle (tools/calib/issue_probe.hip), so
 // throughput follows the number of resident workgroups almost 1 : 1.  fp64 at N >= 40: 56 ... 74 KB of LDS allow two (256 VGPRs, no scratch); at
 // N = 32 / 36 the 44 / 50 KB allow three, which is worth the scratch that 168 VGPRs cost: 1.62 -> 2.14 and 1.39 -> 1.85 M solves/s at B = 262 144.
-// fp32: four (128 VGPRs), five up to N = 36 (+8 / +13 %; N = 40 gained 2 % and, once the degenerate-pair rule added a register, spilled inside a
-// divergent region -- tools/spill_exec_check.py -- so it stays at four).
+// fp32: four (128 VGPRs), five up to N = 40 (+8 / +13 / +2 % at N = 32 / 36 / 40).
 template <typename T, int N>
-__global__ __launch_bounds__(256, sizeof(T) == 8 ? (N <= 36 ? 3 : 2) : (N <= 36 ? 5 : 4)) void kmpc_solve_wide_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? (N <= 36 ? 3 : 2) : (N <= 40 ? 5 : 4)) void kmpc_solve_wide_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WideSolver<T, N>::lds_elems() * sizeof(T)];
     ipm::run_solver<WideSolver<T, N>>(P, io, smem);

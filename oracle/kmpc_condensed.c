@@ -466,6 +466,7 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
     const double x_degen = getenv("KMPC_X_DEGEN") ? atof(getenv("KMPC_X_DEGEN")) : 0.6;
     double *thu = (double *)malloc((size_t)2 * nf * sizeof(double)), *thl = thu + nf;
     for (int f = 0; f < 2 * nf; ++f) thu[f] = 1.0;
+    int *cand = (int *)calloc((size_t)nf, sizeof(int));
     double dw_last = 0.0, dw_spec = 0.0, hmax_prev = 0.0, reg_final = 0.0;
     /* Tuned on the pooled worst-of-4096 statistics of 48 seeded batches (the kernels carry the same values):
        after a failed first trial (= last/3) the shift grows x3 -- back to the one that worked last iteration -- instead of x8;
@@ -722,6 +723,12 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
                 if (dsl < 0.0) ap = fmin(ap, -tau * sl[f] / dsl);
                 if (dlu[f] < 0.0) ad = fmin(ad, -tau * lu[f] / dlu[f]);
                 if (dll[f] < 0.0) ad = fmin(ad, -tau * ll[f] / dll[f]);
+                {   /* shares of the slack and of its multiplier that the full step takes off; the signature of a degenerate pair: both above 0.3 and within
+                       0.2 of each other.  (Also requiring the side to be near its bound or its product well above mu changes nothing or costs iterations:
+                       7.18 against 7.10 mean at N = 20) */
+                    const double qsu = -dsu / su[f], qsl = -dsl / sl[f], qlu = -dlu[f] / lu[f], qll = -dll[f] / ll[f];
+                    cand[f] = ((qsu > 0.3 && qlu > 0.3 && fabs(qsu - qlu) < 0.2) ? 1 : 0) | ((qsl > 0.3 && qll > 0.3 && fabs(qsl - qll) < 0.2) ? 2 : 0);
+                }
             }
             /* Armijo on phi_mu(U) = sc*J(U) - mu*sum log s along du; d phi/d alpha = (sc*g + A^T(mu/s_u - mu/s_l))^T du */
             double phi0 = sc * J, dphi = gw;
@@ -760,13 +767,12 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
         full_prev = alpha >= 1.0 && ad >= 1.0;   /* the accepted step was a full Newton step in the inputs and in the multipliers */
         memcpy(U, Ut, (size_t)n * sizeof(double));
         if (n_tiny >= 2) { status = err0 <= 1e3 * o->tol ? KMPC_OPTIMAL : KMPC_NUMERICAL_ERROR; tiny_stop = 1; break; }
+        /* a candidate (marked where the step was computed, below the fraction-to-the-boundary rule) becomes a degenerate pair when the step was accepted
+           (nearly) in full */
         if (x_degen > 0.0 && x_degen < 1.0) for (int f = 0; f < nf; ++f) {
-            /* the signature: an accepted (nearly) full step took the same share off the slack and off its multiplier.  (Also requiring the side to be near its
-               bound or its product well above mu changes nothing or costs iterations: 7.18 against 7.10 mean at N = 20) */
-            const double rsu = (su[f] - alpha * aut[f]) / su[f], rlu = (lu[f] + ad * dlu[f]) / lu[f];
-            const double rsl = (sl[f] + alpha * aut[f]) / sl[f], rll = (ll[f] + ad * dll[f]) / ll[f];
-            thu[f] = (alpha >= 0.9 && ad >= 0.9 && rsu < 0.7 && rlu < 0.7 && fabs(rsu - rlu) < 0.2) ? x_degen : 1.0;
-            thl[f] = (alpha >= 0.9 && ad >= 0.9 && rsl < 0.7 && rll < 0.7 && fabs(rsl - rll) < 0.2) ? x_degen : 1.0;
+            const int full = alpha >= 0.9 && ad >= 0.9;
+            thu[f] = (full && (cand[f] & 1)) ? x_degen : 1.0;
+            thl[f] = (full && (cand[f] & 2)) ? x_degen : 1.0;
         }
         for (int f = 0; f < nf; ++f) {
             su[f] -= alpha * aut[f];
@@ -788,6 +794,7 @@ finish:
     }
     free(Ubest);
     free(thu);
+    free(cand);
     kmpc_rollout_m(p, q->k_poly, q->z0, U, Xl);
     if (X)
         for (int k = 0; k <= N; ++k) {
