@@ -625,10 +625,11 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
     // cancellation once an active slack is ~1e-9
     T sup[NF], slo[NF], isu[NF], isl[NF], lu[NF], ll[NF], aut[NF], w[NF];  // isu/isl = 1/slack, refreshed when the slacks move
     bool fv[NF];
-    // degenerate pairs (slack and multiplier vanish together: Newton halves them per iteration, x0.375 with the corrector): a side of a form that was seen
-    // shrinking that way in the last accepted full step enters K (and the recovery of its multiplier step, consistently) with its barrier stiffness lambda/s
-    // scaled by KMPC_DEGEN_THETA -- the step of a double root.  The mark is the lowest mantissa bit of the side's reciprocal slack (isu / isl are refreshed
-    // exactly where the mark is decided, in the acceptance block below; one ulp of a Newton-refined reciprocal): no register, no LDS.
+    // degenerate pairs (slack and multiplier vanish together: Newton halves them per iteration, x0.375 with the corrector; kmpc_common.h): a side of a form
+    // whose slack and multiplier the last accepted full step shrank by similar shares enters K (and the recovery of its multiplier step, consistently) with
+    // its barrier stiffness lambda/s scaled by KMPC_DEGEN_THETA -- the step of a double root.  Candidates are marked where the step is computed (its step-length
+    // shares are the signature; two lowest mantissa bits of a_f^T du), a candidate becomes a mark when the step is accepted in full: the lowest mantissa bit of
+    // the side's reciprocal slack, refreshed in that very place (one ulp of a Newton-refined reciprocal).  No register, no LDS.
     // (theta is re-derived from the bit at every use -- an integer AND, a conversion and an fma behind an opaque barrier: left to itself the compiler keeps the
     // 2 NF selected factors in registers across the iteration, which the kernels at their register limit pay with 40 more spilled registers)
     // fp64 only: the fp32 solves end at their rounding floor (error ~1e-4) before a degenerate pair's tail begins -- measured: no iteration saved, 2.5 % of
