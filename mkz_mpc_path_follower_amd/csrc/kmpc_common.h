@@ -42,6 +42,17 @@
 #ifndef KMPC_DEGEN_THETA
 #define KMPC_DEGEN_THETA 0.6
 #endif
+// Run-time guard of the slack iterates (kmpc_ipm.h, ipm::solve): an iterate is reported Optimal only if every live slack agrees with the freshly
+// evaluated b -/+ a_f^T U to this tolerance, relative to max(1, |bound|, |a_f^T U|).  Rounding alone: <= 2.7e-15 (fp64) / <= 1.6e-6 (fp32) measured over
+// seeded draws of up to 262 144 problems at N = 8 ... 50, every kernel family (tools/drift_probe.py -> profiles/r4_slack_drift.txt) -- the tolerances sit
+// five / two decades above that, and two / one decade below
+// the drift that moved round 3's non-KKT "Optimal" (complementarity 9e-3).
+#ifndef KMPC_DRIFT_TOL_F64
+#define KMPC_DRIFT_TOL_F64 1e-9
+#endif
+#ifndef KMPC_DRIFT_TOL_F32
+#define KMPC_DRIFT_TOL_F32 1e-4
+#endif
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
@@ -141,6 +152,10 @@ DEV double readlane_(double x, int l) {  // l wave-uniform
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 DEV float readlane_(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+// a value that is identical in every lane, handed to the compiler AS wave-uniform (scalar registers): branches on it become scalar branches instead of
+// exec-masked regions -- which is also where this toolchain's allocator has put spill code ahead of the mask restore
+DEV double uniform_(double x) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x))); }
+DEV float uniform_(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
 // inclusive prefix sum over lanes 0..63 (ROWS = number of 16-lane rows that carry data)
 template <int ROWS, typename T> DEV T dpp_scan_prefix(T x) {

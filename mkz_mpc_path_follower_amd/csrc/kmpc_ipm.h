@@ -82,7 +82,9 @@ enum { C_ERR = 0, C_RDS, C_DWL, C_DWS, C_HMAX, C_MUF, C_PHI0, C_DPHI, C_AD, C_J,
 
 namespace ipm {
 
-template <int NTH> DEV void xsync() { if constexpr (NTH == 64) { WFENCE(); } else { __syncthreads(); } }
+// exchange through LDS among the NTH threads of a problem: inside one wave (NTH <= 64: one wave per problem, or a 16-lane row of a wave in the
+// four-per-wave back-end, whose rows branch independently -- a workgroup barrier in divergent code would be undefined) program order is enough
+template <int NTH> DEV void xsync() { if constexpr (NTH <= 64) { WFENCE(); } else { __syncthreads(); } }
 
 template <typename T> DEV void fill_param_table(T *q, const KP &p, int nf)
 {
@@ -655,6 +657,9 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
 #pragma unroll
     for (int i = 0; i < NF; ++i) s.cu(i) = s.cl(i) = (T)0;
     int mode = FIRST;
+#ifdef KMPC_DRIFT_PROBE
+    T drift_probe = (T)-1;
+#endif
     typename SV::stage_t St;
     STAMP_DECL_AT(s)
 
@@ -701,6 +706,37 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
         // the thread indices are re-materialised (opaque) at the top of every iteration: stops LICM from hoisting the index / mask / address
         // arithmetic of every phase out of the loop into registers that then live (and spill) across the whole solve
         s.refresh_ids();
+        // Run-time guard of the slack iterates (round 4).  The slacks are ITERATES (advanced by alpha * a_f^T du) and the termination test trusts them.
+        // Whatever makes one part from b -/+ a_f^T U -- round 3 met register-allocator spill code inside a divergent region that handed masked-off
+        // lanes stale slot contents -- lets the method converge, by its own measure, on a KKT point of a SHIFTED problem.  An
+        // offset, once there, stays (every later update is an increment), so ONE comparison at the end of the solve covers all of its iterates, the
+        // saved best one included: the slacks of the last iterate (U at this point on every path into FINAL) against its freshly evaluated forms.
+        // Drift beyond KMPC_DRIFT_TOL * max(1, |bound|, |a_f^T U|) on any live form => KMPC_NUMERICAL_ERROR, never Optimal (tolerances: kmpc_common.h).
+        if (mode == FINAL && status != 2) {
+            s.forms_apply(U, w);
+            T drifted = (T)0;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                T bu_, bl_;
+                s.form_bounds(s.vid + NTH * i, bu_, bl_);
+                const T lim = (T)(sizeof(T) == 8 ? KMPC_DRIFT_TOL_F64 : KMPC_DRIFT_TOL_F32) * fmax((T)1, fmax(fmax(fabs(bu_), fabs(bl_)), fabs(w[i])));
+                const bool ok_ = fabs(sup[i] - (bu_ - w[i])) <= lim && fabs(slo[i] - (bl_ + w[i])) <= lim;   // (false for NaN)
+                drifted = fv[i] && !ok_ ? (T)1 : drifted;
+            }
+            if (s.max_any(drifted) > (T)0) { status = 3; have_best = false; }
+#ifdef KMPC_DRIFT_PROBE   // diagnostic build (make driftprobe): the violation output carries the largest relative drift of the last iterate's slacks instead
+            drift_probe = (T)0;
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                if (fv[i]) {
+                    T bu_, bl_;
+                    s.form_bounds(s.vid + NTH * i, bu_, bl_);
+                    const T sc_ = fmax((T)1, fmax(fmax(fabs(bu_), fabs(bl_)), fabs(w[i])));
+                    drift_probe = fmax(drift_probe, fmax(fabs(sup[i] - (bu_ - w[i])), fabs(slo[i] - (bl_ + w[i]))) / sc_);
+                }
+            drift_probe = s.max_any(drift_probe);
+#endif
+        }
         if (mode == FINAL && have_best && !tiny_stop && !(status == 0 && cs[C_ERR] <= s.pt[PT_TOL])) {
             // any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed
             s.load_best(Ut);
@@ -783,6 +819,10 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
                 const int cb = DGR && full_step ? lsb2_get(aut[i]) : 0;
                 isu[i] = fv[i] ? lsb_set(rcp_(sup[i]), (cb & 1) != 0) : (T)0; isl[i] = fv[i] ? lsb_set(rcp_(slo[i]), (cb & 2) != 0) : (T)0;
             }
+#ifdef KMPC_CORRUPT_SLACK   // diagnostic build (make corrupt; tests/test_gpu_parity.py): what round 3's hazard did -- one thread's slack iterate parts from b - a_f^T U
+                            // in mid-solve (consistently: its reciprocal follows) -- to show that the guard turns the resulting "Optimal" into an Error
+            if (iters == 2 && s.vid == 5) { sup[0] += (T)KMPC_CORRUPT_SLACK; isu[0] = lsb_set(rcp_(sup[0]), false); }
+#endif
         }
         const bool restep = mode == RESTEP;
         if (!restep) {
@@ -1054,7 +1094,11 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
     if (s.vid == 0) {
         io.status[b] = status;
         if (io.cost) io.cost[b] = Jt;
+#ifdef KMPC_DRIFT_PROBE
+        if (io.viol) io.viol[b] = drift_probe;
+#else
         if (io.viol) io.viol[b] = viol;
+#endif
         if (io.iters) io.iters[b] = iters;
     }
 }

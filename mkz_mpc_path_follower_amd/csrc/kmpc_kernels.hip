@@ -255,7 +255,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         T Jl = Cx * S.ex * S.ex + Cy * S.ey * S.ey + Cp * S.ep * S.ep + Cv * S.ev * S.ev;  // (:97-98)
         if (st) Jl += Ca * a * a + Cd * d * d;                                             // (:99-100)
         if (k < N - 1) Jl += Cda * (an - a) * (an - a) + Cdd * (dn - d) * (dn - d);        // (:101-102)
-        return wave_sum(Jl);
+        return uniform_(wave_sum(Jl));
     }
 
     // ---- (b) costates, gradient (n-vector g) and per-stage scalars for the condensing loop -------
@@ -476,7 +476,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         T Jl = Cx * S.ex * S.ex + Cy * S.ey * S.ey + Cp * S.ep * S.ep + Cv * S.ev * S.ev;  // Frenet.jl:97-98 (C_x = 0)
         if (st) Jl += Ca * a * a + Cd * d * d;
         if (k < N - 1) Jl += Cda * (an - a) * (an - a) + Cdd * (dn - d) * (dn - d);
-        return wave_sum(Jl);
+        return uniform_(wave_sum(Jl));
     }
 
     // stage record of the Frenet functor: A00 A01 A02 A03 A12 A13 A20 A21 A22 A23 Bs Bey Bep  (A11 = A33 = 1, B_v,acc = dt)
@@ -809,7 +809,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
         {
             const T rxn = __shfl_down(rx, 1), ryn = __shfl_down(ry, 1);
             const T seg = (lane >= 1 && lane < N) ? sqrt((rxn - rx) * (rxn - rx) + (ryn - ry) * (ryn - ry)) : (T)0;
-            len = wave_sum(seg);
+            len = uniform_(wave_sum(seg));
             kap = (readlane_(rp, N) - readlane_(rp, 1)) / fmax(len, (T)1e-6);
         }
         if (MODEL == 1) kap = ((kp0 * x0 + kp1) * x0 + kp2) * x0 + kp3;  // Frenet: curvature of the polynomial at s0
@@ -880,16 +880,16 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
     template <int NS, int NM> DEV void reduce(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM]) const
     {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) sm[i] = wave_sum(sm[i]);
+        for (int i = 0; i < NS; ++i) sm[i] = uniform_(wave_sum(sm[i]));   // (the butterfly leaves bit-identical values in every lane)
 #pragma unroll
-        for (int i = 0; i < NM; ++i) mx[i] = wave_max(mx[i]);
+        for (int i = 0; i < NM; ++i) mx[i] = uniform_(wave_max(mx[i]));
     }
     template <int NS, int NM> DEV void reduce_flag(T (&sm)[NS < 1 ? 1 : NS], T (&mx)[NM < 1 ? 1 : NM], bool &all_true) const
     {
         all_true = __all(all_true);
         reduce<NS, NM>(sm, mx);
     }
-    DEV T max_any(T x) const { return wave_max(x); }
+    DEV T max_any(T x) const { return uniform_(wave_max(x)); }
     DEV void form_bounds(int f, T &bu, T &bl) const { T rlx; form_bounds(f, bu, bl, rlx); }
     DEV T form_relax(int f, bool upper) const   // the relaxation contained in form_bounds (speed forms relax upper / lower separately)
     {
@@ -932,7 +932,7 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
                         for (int r = 0; r < 4; ++r)
                             if (Real<T>::row_of(lane, r) == (lane & 15)) hm = fmax(hm, fabs(sc * acc[LDSACC ? 0 : ti * (ti + 1) / 2 + ti][r]));
                 }
-                cs[C_HMAX] = wave_max(hm);
+                cs[C_HMAX] = uniform_(wave_max(hm));
             }
         }
         STAMP(3);

@@ -785,6 +785,18 @@ int kmpc_condensed_solve(const kmpc_params *p, const kmpc_problem *q_in, const k
     }
 
 finish:
+    /* Run-time guard of the slack iterates (same rule as ipm::solve in csrc/kmpc_ipm.h, round 4): the slacks are iterates and the termination test trusts
+       them; an offset between a slack and b -/+ a_f^T U, once there, stays (every update is an increment), so one comparison of the LAST iterate's slacks
+       with its freshly evaluated forms covers every iterate of the solve, the saved best one included.  Beyond 1e-9 relative: Error, never Optimal. */
+    if (status != KMPC_INFEASIBLE) {
+        int drifted = 0;
+        forms_apply(&F, U, au);
+        for (int f = 0; f < nf; ++f) {
+            const double lim = 1e-9 * fmax(1.0, fmax(fmax(fabs(bu[f]), fabs(bl[f])), fabs(au[f])));
+            if (!(fabs(su[f] - (bu[f] - au[f])) <= lim && fabs(sl[f] - (bl[f] + au[f])) <= lim)) drifted = 1;
+        }
+        if (drifted) { status = KMPC_NUMERICAL_ERROR; have_best = 0; }
+    }
     /* any later trouble (polishing noise, line-search failure, iteration cap) returns the iterate that passed */
     if (have_best && !(status == KMPC_OPTIMAL && err0 <= o->tol) && !tiny_stop) {
         memcpy(U, Ubest, (size_t)n * sizeof(double));

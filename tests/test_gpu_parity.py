@@ -453,3 +453,22 @@ def test_further_seeded_draws_are_all_optimal(N, cfg, B, dtype):
         st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
         assert (st == 0).all(), (k, np.bincount(st))
         assert it.max() <= 120, (k, it.max())
+
+
+def test_slack_guard_trips_on_a_corrupted_slack():
+    """The run-time guard of ipm::solve (round 4; VERDICT r3 item 1): round 3 met register-allocator spill code inside a divergent region that handed
+    masked-off lanes stale slot contents -- slack iterates drifted from b - a_f^T U and the solver reported a non-KKT point Optimal.  The TEST build
+    libkmpc_hip_corrupt.so does that on purpose (thread 5's first slack, +1e-3 after the second accepted step, in every solve): every kernel family --
+    one wave per problem, four problems per wave, four waves per problem, generic; both precisions -- must now return KMPC_NUMERICAL_ERROR for every
+    problem and Optimal for none.  (Child process: the shipped library stays the one this process has loaded.)"""
+    import json, os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(os.path.dirname(here), "mkz_mpc_path_follower_amd", "libkmpc_hip_corrupt.so")
+    assert os.path.exists(lib), "build it: make -C mkz_mpc_path_follower_amd/csrc (the default target builds it)"
+    r = subprocess.run([sys.executable, os.path.join(here, "_corrupt_probe.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("CORRUPT_PROBE ")][-1]
+    counts = json.loads(line[len("CORRUPT_PROBE "):])
+    assert len(counts) == 11
+    for label, (n_opt, n_lim, n_inf, n_err) in counts.items():
+        assert n_opt == 0 and n_lim == 0 and n_inf == 0 and n_err > 0, (label, counts[label])
