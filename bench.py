@@ -393,6 +393,9 @@ def main():
     ap.add_argument("--quick", action="store_true", help="skip the multi-seed and other-config extra keys")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank control flow on a one-GPU box)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the asynchronous RCCL all-gather of the N > 1 loop also at --gpus 1 (1-rank nccl group): prices the collective's overhead on one GPU "
+                         "and puts the RCCL path under test before multi-GPU hardware shows up (tests/test_bench_cli.py)")
     a = ap.parse_args()
     # dmabuf IPC only on this pool (RCCL / cross-process tensors fail with hipIpcGetMemHandle otherwise): already exported on the boxes; set before the
     # first HIP call in case a launcher dropped it
@@ -416,7 +419,15 @@ def main():
         local = local % torch.cuda.device_count()  # rehearsal: the ranks share the box's GPU(s)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    forced = a.force_collective and world == 1
+    if forced:   # a 1-rank group of its own: rendezvous on a free local port
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -444,7 +455,7 @@ def main():
     # solved; K output slots alternate (a rank may run up to K steps ahead of the slowest one -- over K steps every rank has done the same
     # work), and a slot's gather is waited for before a solve may overwrite the buffer it reads.
     # Every step's gather completes inside the timed region (final waits + synchronize below).
-    gather = SolutionGather(B, slots=K)
+    gather = SolutionGather(B, slots=K, force_collective=forced)
     outs = [None] * K
 
     # (host-side set-up of the timed loop comes BEFORE the warm-up, so that nothing but the synchronisation sits between the last warm-up launch and t0)
@@ -483,6 +494,25 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    # untimed: K more steps through the same loop, every gathered [B, 2] block compared with the blocks the ranks solved (this rank's own block exactly;
+    # with N > 1 also the block every other rank reports for the same draw -- all ranks solve the same K draws, rotated, and the kernels are deterministic)
+    gather_checked, gather_ok = 0, True
+    if world > 1 or forced:
+        own = {}
+        for i in range(K):
+            s = i % K
+            dj = dins[(i + rank) % K]
+            outs[s] = solver.solve(dj["z0"], dj["ref"], dj["v_target"], dj["u_prev"], out=outs[s])
+            gather.submit(s, outs[s]["u0"])
+            own[(i + rank) % K] = outs[s]["u0"].clone()
+        for i in range(K):
+            s = i % K
+            g = gather.wait(s)
+            torch.cuda.synchronize()
+            for r in range(world):
+                blk = g[r * Bl:(r + 1) * Bl]
+                gather_ok = gather_ok and bool(torch.equal(blk, own[(i + r) % K]))
+                gather_checked += 1
     kern = np.array([e[1].elapsed_time(e[2]) for e in ev])
     kern_ms = float(kern.mean())
     wait_stream_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
@@ -528,7 +558,11 @@ def main():
             "config": {"workload": cfg_label + "; every rank cycles through the same %d seeded draws (rank r solves draw (step + r) %% %d)" % (K, K),
                        "batch_per_gpu": Bl, "global_batch": B, "horizon": N, "parallelism": "shard%d" % world, "draws": K,
                        "draw_seeds": [20180620 + 2 + 7919 * j for j in range(K)], "kernel_ms_per_draw": per_draw_ms,
-                       "mean_iterations": iters, "optimal_fraction": n_opt / n_tot},
+                       "mean_iterations": iters, "optimal_fraction": n_opt / n_tot,
+                       "collective": ("none (one rank)" if (world == 1 and not forced) else
+                                      "%s all_gather_into_tensor(async_op=True) of the [%d, 2] (accel, steer) block per step, %d slots%s"
+                                      % ("RCCL" if a.backend == "nccl" else "gloo", Bl, K, ", forced in a 1-rank group" if forced else "")),
+                       "gather_blocks_checked": gather_checked, "gather_blocks_equal_to_the_ranks_solutions": gather_ok},
             # the path is compute/latency-bound.  The SQ counters (profiles/r*_sq_counters.json) say the kernel is bound by
             # fp64 VALU ISSUE while the chip is full and by single-wave latency in the tail, not by the matrix cores; the denominator is the
             # fp64 vector = fp64 MFMA peak (78.6 TFLOP/s), the numerator the flops the kernel EXECUTES per launch (the SURVEY 8(d) model,
@@ -592,7 +626,7 @@ def main():
                 # parity spot check of the timed batch against the CPU port on the sampled problems
                 res["parity_sample"] = parity_sample(N, d, out, ro)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

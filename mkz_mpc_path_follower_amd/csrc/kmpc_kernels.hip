@@ -836,23 +836,22 @@ template <typename T, int NT, int MODEL = 0> struct Solver {
             const T push = (T)0.25 * (hi - lo);
             u0[j] = fmin(fmax(j ? dff : aff, lo + push), hi - push);
         }
-        const T vm = fmin((T)1, (T)0.25 * ((T)P.v_max - (T)P.v_min)), acap = (T)0.5 * (T)P.a_max;
-        const T astep = frac * (T)P.a_dmax * dt, dstep = frac * (T)P.steer_dmax * dt;
-        T v = v0 + dt * u0[0], ap = u0[0], dp = u0[1];
+        // later inputs: strictly feasible by construction (round 4; the rule and its argument: ipm::interior_point in kmpc_ipm.h)
+        const T vm = fmin((T)1, (T)0.25 * ((T)P.v_max - (T)P.v_min));
+        const T dstep = frac * (T)P.steer_dmax * dt;
+        const T vstar = fmin(fmax(vref, (T)P.v_min + vm), (T)P.v_max - vm);
+        T v = v0 + dt * u0[0], dp = u0[1];
 #pragma unroll
         for (int i = 0; i < NV; ++i) Uf[i] = (T)0;
         if (lane == 0) Uf[0] = u0[0];
         if (lane == 1) Uf[0] = u0[1];
         for (int k = 1; k < N; ++k) {  // uniform scalar recurrence, N steps
-            T a = ffw * fmin(fmax(vref - v, -frac * (T)P.a_max), frac * (T)P.a_max);
-            a = fmin(fmax(a, ap - astep), ap + astep);
-            if (v + dt * a < (T)P.v_min + vm) a = fmin((T)P.v_min + vm - v, acap);
-            else if (v + dt * a > (T)P.v_max - vm) a = fmax((T)P.v_max - vm - v, -acap);
+            const T a = ffw * fmin(fmax(vstar - v, -frac * (T)P.a_max), frac * (T)P.a_max);
             const T d = fmin(fmax(dff, dp - dstep), dp + dstep);
             const int j = 2 * k;
 #pragma unroll
             for (int i = 0; i < NV; ++i) { if (lane + 64 * i == j) Uf[i] = a; if (lane + 64 * i == j + 1) Uf[i] = d; }
-            v += dt * a; ap = a; dp = d;
+            v += dt * a; dp = d;
         }
         return ok;
     }

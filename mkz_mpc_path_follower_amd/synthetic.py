@@ -57,3 +57,64 @@ def straight_line_case(N, v0=0.0, y0=0.0, psi0=0.0, v_ref=15.0, dt=0.2):
     ref[0, :, 0] = v_ref * dt * np.arange(N + 1)
     z0 = np.array([[0.0, y0, psi0, v0]])
     return dict(z0=z0, ref=ref, v_target=np.array([v_ref]), u_prev=np.zeros((1, 2)), hard=np.array([False]))
+
+
+def _feasible_acc_prev(acc_prev, v0, dt, v_max=20.0):
+    """keep the first-step rate interval (|acc_1 - acc_prev| <= 0.15) compatible with 0 <= v0 + dt * acc_1 <= v_max (see make_batch)"""
+    return np.minimum(np.maximum(acc_prev, -v0 / dt - 0.10), (v_max - v0) / dt + 0.10)
+
+
+def make_ood_batch(B, N, seed, paths=None, dt=0.2, dtype=np.float64):
+    """Out-of-distribution batch (tools/ood_sweep.py, tests/test_gpu_parity.py): far wider than make_batch on every axis the iteration's
+    rules were tuned on -- heading error N(0, 0.3 rad), lateral error U(-4, 4) m, initial speed U(0, 20) m/s INDEPENDENT of the reference's speed, previous
+    command anywhere in the input box.  Two reference families, half of the batch each (all of it family A when `paths` is None):
+      A  circular arcs with |kappa| <= 0.2 1/m (twice the recorded paths' range) at 0.5 ... 11 m/s;
+      B  time-mode windows of the recorded paths (ref_gps_traj.py:186-195: N + 1 samples of the recorded x, y, psi at t_i + 0.2 h, so the spacing follows
+         the recorded speed profile, 0.5 ... 11 m/s, including windows that run into the path's end, where np.interp clamps and the waypoints coincide),
+         `paths` = list of dicts with t, x, y, psi (the fixtures tests/golden/path*_decimated.npz); psi is unwrapped against the vehicle's heading as the
+         helper does (:204-218).
+    returns the make_batch dict + family[B] (0 = A, 1 = B)"""
+    rng = np.random.default_rng(seed)
+    fam = (rng.uniform(size=B) < 0.5).astype(np.int64) if paths else np.zeros(B, dtype=np.int64)
+    e_y = rng.uniform(-4.0, 4.0, B)
+    e_psi = rng.normal(0.0, 0.3, B)
+    v0 = rng.uniform(0.0, 20.0, B)
+    acc_prev = _feasible_acc_prev(rng.uniform(-1.0, 1.0, B), v0, dt)
+    df_prev = rng.uniform(-0.5, 0.5, B)
+    # family A
+    kappa = rng.uniform(-0.2, 0.2, B)
+    v_t = rng.uniform(0.5, 11.0, B)
+    th0 = rng.uniform(-np.pi, np.pi, B)
+    s = v_t[:, None] * dt * np.arange(N + 1)[None, :]
+    ks = kappa[:, None] * s
+    small = np.abs(kappa)[:, None] < 1e-9
+    ksafe = np.where(small, 1.0, kappa[:, None])
+    xr = np.where(small, s * np.cos(th0)[:, None], (np.sin(th0[:, None] + ks) - np.sin(th0)[:, None]) / ksafe)
+    yr = np.where(small, s * np.sin(th0)[:, None], -(np.cos(th0[:, None] + ks) - np.cos(th0)[:, None]) / ksafe)
+    pr = th0[:, None] + ks
+    x0, y0, h0 = np.zeros(B), np.zeros(B), th0.copy()
+    if paths:
+        which = rng.integers(0, len(paths), B)
+        for k, P in enumerate(paths):
+            m = np.where((fam == 1) & (which == k))[0]
+            if len(m) == 0:
+                continue
+            t, px, py, pp = (np.asarray(P[c], dtype=np.float64) for c in ("t", "x", "y", "psi"))
+            i0 = rng.integers(0, len(t), len(m))
+            grid = t[i0][:, None] + dt * np.arange(N + 1)[None, :]
+            xr[m] = np.interp(grid.ravel(), t, px).reshape(grid.shape)
+            yr[m] = np.interp(grid.ravel(), t, py).reshape(grid.shape)
+            pr[m] = np.interp(grid.ravel(), t, pp).reshape(grid.shape)          # interpolated BEFORE unwrapping, as the reference does (Q8)
+            x0[m], y0[m], h0[m] = px[i0], py[i0], pp[i0]
+            v_t[m] = 1.0                                                         # des_speed of the launch file; C_v = 0
+    psi0 = h0 + e_psi
+    if paths:   # the helper's wrap fix (:204-218), vectorised: candidates p, p + 2 pi, p - 2 pi closest to the vehicle's heading, for the rows that fail its two checks
+        m = np.where(fam == 1)[0]
+        bad = (np.abs(np.diff(pr[m], axis=1)).max(1) >= np.pi) | (np.abs(pr[m] - psi0[m, None]).max(1) >= np.pi)
+        mm = m[bad]
+        c = np.stack([pr[mm], pr[mm] + 2 * np.pi, pr[mm] - 2 * np.pi], -1)
+        pr[mm] = np.take_along_axis(c, np.abs(c - psi0[mm, None, None]).argmin(-1)[..., None], -1)[..., 0]
+    ref = np.stack([xr, yr, pr], axis=-1)
+    z0 = np.stack([x0 - e_y * np.sin(h0), y0 + e_y * np.cos(h0), psi0, v0], axis=-1)
+    u_prev = np.stack([acc_prev, df_prev], axis=-1)
+    return dict(z0=z0.astype(dtype), ref=ref.astype(dtype), v_target=v_t.astype(dtype), u_prev=u_prev.astype(dtype), hard=np.zeros(B, dtype=bool), family=fam)

@@ -396,17 +396,26 @@ static int interior_point(const kmpc_params *p, const kmpc_problem *q, double re
         const double push = 0.25 * (hi - lo);
         Uf[j] = fmin(fmax(j ? dff : aff, lo + push), hi - push);
     }
-    const double vm = fmin(1.0, 0.25 * (p->v_max - p->v_min)), acap = 0.5 * p->a_max;
-    const double amax_step = frac * p->a_dmax * p->dt, dmax_step = frac * p->steer_dmax * p->dt;
-    double v = q->z0[3] + p->dt * Uf[0], ap = Uf[0], dp = Uf[1];
+    /* Later inputs.  Round 4 (out-of-distribution sweep): until then a speed-margin override inside this loop could jump the
+       acceleration by more than the rate rows allow (cars below 1 m/s or above 19 m/s that the feed-forward law decelerates / accelerates: 0.2-0.5 % of
+       wide-distribution draws started outside a rate row and ended as Error after one iteration).  Now the start is strictly feasible BY CONSTRUCTION
+       whenever the first input's interval above is non-empty -- which is exactly when the reference's NLP is feasible (a_1 is not tied to a_0, Q1, and
+       zero later accelerations keep v_1):
+         * the acceleration law a_k = clamp(v* - v_k, +-0.6 a_max) (time constant 1 s) towards the reference speed clamped INTO the speed interval's
+           margin, v* = clamp(vref, v_min + vm, v_max - vm), from k = 1 on, where the jump from a_0 is free (MKZMPCPathFollower.jl:77-79: the rate
+           loop starts at i = 2, Q1);
+         * v then approaches v* monotonically (|v* - v| shrinks by dt per step or by dt * a where the law is clipped), so the speed rows hold with
+           at least the slack v_1 has, and |a_{k+1} - a_k| <= dt |a_k| <= 0.12 a_max < a_dmax dt: every later rate row holds with slack >= 0.18;
+         * start = 1 (the reference's all-zero start): a_k = 0, v stays at v_1. */
+    const double vm = fmin(1.0, 0.25 * (p->v_max - p->v_min));
+    const double dmax_step = frac * p->steer_dmax * p->dt;
+    const double vstar = fmin(fmax(vref, p->v_min + vm), p->v_max - vm);
+    double v = q->z0[3] + p->dt * Uf[0], dp = Uf[1];
     for (int k = 1; k < N; ++k) {
-        double a = ffw * fmin(fmax((vref - v) / T, -frac * p->a_max), frac * p->a_max);
-        a = fmin(fmax(a, ap - amax_step), ap + amax_step);
-        if (v + p->dt * a < p->v_min + vm) a = fmin(p->v_min + vm - v, acap);       /* keep the speed rows strictly inside */
-        else if (v + p->dt * a > p->v_max - vm) a = fmax(p->v_max - vm - v, -acap);
+        const double a = ffw * fmin(fmax((vstar - v) / T, -frac * p->a_max), frac * p->a_max);
         const double d = fmin(fmax(dff, dp - dmax_step), dp + dmax_step);
         Uf[2 * k] = a; Uf[2 * k + 1] = d;
-        v += p->dt * a; ap = a; dp = d;
+        v += p->dt * a; dp = d;
     }
     return 0;
 }

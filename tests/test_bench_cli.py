@@ -64,3 +64,23 @@ def test_bench_launches_its_own_ranks():
         assert len(rk[k]) == 2 and all(v >= 0 for v in rk[k]), k
     assert rk["summary"]["kernel_ms"]["min"] <= rk["summary"]["kernel_ms"]["mean"] <= rk["summary"]["kernel_ms"]["max"]
     assert d["config"]["draws"] == 4 and "rank r solves draw" in d["config"]["workload"]
+    assert d["config"]["gather_blocks_checked"] == 8 and d["config"]["gather_blocks_equal_to_the_ranks_solutions"] and d["config"]["collective"].startswith("gloo")
+
+
+def test_bench_forced_collective_runs_rccl_in_a_one_rank_group():
+    """the RCCL path of the N > 1 loop under test before multi-GPU hardware shows up.  A fresh child process (no GPU call before the
+    process group exists) runs `bench.py --gpus 1 --force-collective`: init_process_group("nccl", world_size=1, device_id=...), the K-slot asynchronous
+    all_gather_into_tensor of every step's (accel, steer) block on the collective's stream, every gathered block compared with the step's own solution,
+    and the per-rank wait times reported.  Its JSON line is kept under profiles/ (copied there from gpurun_out/ by hand: the test writes gpurun_out/)."""
+    d = _run(["--gpus", "1", "--force-collective", "--steps", "8", "--warmup", "2", "--quick", "--no-cpu-baseline"])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["collective"].startswith("RCCL all_gather_into_tensor(async_op=True)") and "forced in a 1-rank group" in c["collective"]
+    assert c["gather_blocks_checked"] == 4 and c["gather_blocks_equal_to_the_ranks_solutions"] is True and c["optimal_fraction"] == 1.0
+    rk = d["ranks"]
+    assert len(rk["gather_wait_stream_ms"]) == 1 and rk["gather_wait_stream_ms"][0] >= 0 and rk["gather_wait_host_ms"][0] >= 0
+    # the collective is overlapped: a step costs at most a few per cent more than its kernel (measured: 0.47 vs 0.46 ms)
+    assert d["ms_per_step"] <= 1.25 * rk["kernel_ms_mean"][0] + 0.05
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "rccl_one_rank_bench.json"), "w") as f:
+        json.dump(d, f)

@@ -472,3 +472,31 @@ def test_slack_guard_trips_on_a_corrupted_slack():
     assert len(counts) == 11
     for label, (n_opt, n_lim, n_inf, n_err) in counts.items():
         assert n_opt == 0 and n_lim == 0 and n_inf == 0 and n_err > 0, (label, counts[label])
+
+
+@pytest.mark.parametrize("N,kv", [(8, 0), (8, 1), (20, 0), (50, 0)])
+def test_degenerate_pair_marks_survive_on_the_gpu(oracle, monkeypatch, N, kv):
+    """the degenerate-pair rule's marks ride in mantissa bits (lowest bit of a side's reciprocal slack, two lowest bits of a_f^T du:
+    kmpc_ipm.h) -- one refactor that recomputes a reciprocal without re-applying the mark would silently disable the rule.  The reference's
+    module-load problem (MKZMPCPathFollower.jl:36-39,110-113,127; a standing start that accelerates at the limit to the end of the horizon: the
+    structural degenerate pair) and the bench batch's standing start #3694 must take on the GPU exactly the iteration count of the CPU port WITH the
+    rule, which is at least two fewer than the port's without it (N = 8: 9 against 13)."""
+    O = oracle
+    d = straight_line_case(N, v0=0.0)
+    r = _solve(N, d, kernel_variant=kv)
+    p = O.params(N)
+    args = (p, d["z0"], d["ref"], d["v_target"], d["u_prev"])
+    ron = O.solve_condensed_batch(*args, nthreads=1)
+    monkeypatch.setenv("KMPC_X_DEGEN", "1")
+    roff = O.solve_condensed_batch(*args, nthreads=1)
+    monkeypatch.delenv("KMPC_X_DEGEN")
+    assert r["status"][0] == 0 and ron["status"][0] == 0 and roff["status"][0] == 0
+    assert int(r["iters"][0]) == int(ron["iters"][0]) <= int(roff["iters"][0]) - 2, (r["iters"], ron["iters"], roff["iters"])
+    if N == 8:
+        assert int(r["iters"][0]) == 9 and int(roff["iters"][0]) == 13
+    if N == 20 and kv == 0:
+        db = make_batch(4096, 20, cfg_id=2)
+        one = {k: db[k][3694:3695] for k in ("z0", "ref", "v_target", "u_prev")}
+        rb = _solve(20, one)
+        rc = O.solve_condensed_batch(p, one["z0"], one["ref"], one["v_target"], one["u_prev"], nthreads=1)
+        assert int(rb["iters"][0]) == int(rc["iters"][0]) and np.abs(rb["U"][0, 1:, 0] - 1.0).max() <= 1e-4
