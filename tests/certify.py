@@ -31,6 +31,7 @@ import numpy as np
 from scipy.optimize import nnls
 
 THRESHOLDS = (1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, np.inf)
+AUG_IF_ABOVE_F32 = 1e-3   # ... for fp32 solutions (callers pass bound_relax 1e-5): their certificates sit at 1e-4 ... 1e-2 whatever the multipliers
 AUG_IF_ABOVE = 2e-8   # the all-rows least-squares candidates are tried while the best active-set certificate is worse than this (STRICT scale)
 WIDE_FROM, WIDE_IF_ABOVE = 1.0, 2e-7   # thresholds >= 1 (NNLS over most rows: tens of ms at N = 50) only while the best certificate is worse than this
 
@@ -78,7 +79,7 @@ def certify_problem(O, p, q, U, relax=1e-8):
     # rows).  An interior-point solution carries multipliers ~mu/slack on every row; where rows with slacks 1e-4 ... 1e-2 still matter to the gradient
     # balance (hard braking into a saturated steering ramp: found by the out-of-distribution sweep) no active-set threshold gives a
     # good certificate although one exists (the solver's own multipliers; the LP that minimises max(stationarity, complementarity) confirms the optimum).
-    if best[0] > AUG_IF_ABOVE:
+    if best[0] > (AUG_IF_ABOVE if relax <= 1e-7 else AUG_IF_ABOVE_F32):
         sp = np.maximum(slack, 0.0)
         # all rows up to N = 20 (m <= 196); beyond, the rows within 0.3 of their bound (the others' multipliers ~mu / slack no longer matter; keeps the NNLS small)
         near = slack <= (np.inf if m <= 200 else 0.3) * np.maximum(1.0, np.abs(b))

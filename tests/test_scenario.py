@@ -19,11 +19,11 @@ import scenario as S
 STEPS = 720   # 72 s: the stop flag latches after 66.2 s, the car stands ~1 s later
 
 
-def _assert_follows(traj, state, cmd, stop, status, what):
+def _assert_follows(traj, state, cmd, stop, status, what, overshoot=0.05):
     sm = S.summarize(traj, state, cmd, stop)
     nl = sm["n_live"]
     assert nl >= 600 and (np.asarray(status)[:nl] == 0).all(), (what, np.bincount(np.asarray(status)[:nl]))
-    assert sm["ect"][100:nl].max() < 0.5 and sm["ect"][:nl].max() < sm["ect"][0] + 0.05, (what, sm["ect"][100:nl].max(), sm["ect"][:nl].max())
+    assert sm["ect"][100:nl].max() < 0.5 and sm["ect"][:nl].max() < sm["ect"][0] + overshoot, (what, sm["ect"][100:nl].max(), sm["ect"][:nl].max())
     assert sm["ect"][50:nl].max() < 0.3, (what, sm["ect"][50:nl].max())                      # measured 0.226
     assert sm["max_dacc"] <= 0.15 + 1.5e-8 and sm["max_ddf"] <= 0.05 + 1.5e-8, (what, sm["max_dacc"], sm["max_ddf"])
     assert np.abs(cmd[:nl, 0]).max() <= 1.0 + 1.5e-8 and np.abs(cmd[:nl, 1]).max() <= 0.5 + 1.5e-8
@@ -83,7 +83,8 @@ def test_launch_scenario_gpu_matches_the_oracle_loop(oracle):
     st, cmd, status, stop = map(np.array, (st, cmd, status, stop))
     tr = grt.get_global_trajectory_reference()
     for b in range(B):
-        _assert_follows(tr, st[:, b], cmd[:, b], stop[:, b], status[:, b], "vehicle %d" % b)
+        # (a car standing up to 0.5 rad off the path's heading first moves away from it: measured up to 0.52 m beyond its initial offset before it turns in)
+        _assert_follows(tr, st[:, b], cmd[:, b], stop[:, b], status[:, b], "vehicle %d" % b, overshoot=0.05 if b == 0 else 1.0)
     ro = S.oracle_closed_loop(O, STEPS)
     n = int((~ro["stop"]).sum())
     assert int((~stop[:, 0]).sum()) == n                                                     # both latch the stop flag in the same control period
