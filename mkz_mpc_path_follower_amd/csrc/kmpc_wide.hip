@@ -16,7 +16,7 @@
 //   * one thread per linear form (nf = 5N-2 = 248 <= 256) and per input (n = 100): every elementwise pass of the interior-point
 //     method is ONE instruction stream of NF = 1; stage vectors (roll-out, costates) are evaluated redundantly by every wave
 //     (lane k = stage k), so their results need no exchange;
-//   * workgroup barriers only where data crosses waves: one per Cholesky block-step, one per reduction; the three triangular
+//   * workgroup barriers only where data crosses waves: one per block-step of the factorisation, one per reduction; the three triangular
 //     substitutions run in wave 0 with two slots per lane (v_readlane broadcasts, no barrier inside).
 #include "kmpc_ipm.h"
 
@@ -195,7 +195,7 @@ template <typename T, int N> struct WideSolver {
         WGSYNC();  // dgs / sbs / the odd rows of the image have been consumed: the panel and the factor may overwrite them
     }
 
-    // ---- blocked Cholesky on the matrix cores (block-LDL^T form, see kmpc_fast.hip), two barriers per 4-column block-step ---------
+    // ---- blocked Cholesky on the matrix cores (block-LDL^T form, see kmpc_fast.hip), ONE barrier per 4-column block-step ---------
     // The panel of block-step jb (columns 4 jb .. 4 jb + 3 of the current Schur complement) goes to LDS from the tile column TC that holds it.
     // TC is a TEMPLATE parameter: the factorisation is unrolled over the tile columns (four block-steps each in a rolled loop), so tile indices,
     // liveness tests and the panel's source registers are all static.  (Until round 3 the tile column was a run-time value and the panel's
@@ -216,13 +216,18 @@ template <typename T, int N> struct WideSolver {
             }
         }
     }
-    // solved panel rows of one tile row (component kk of L for row 16 t + c in lane (c, kk): the MFMA fragment layout), published by the wave that
-    // owns the tile row: rows 0..3 in the staging buffers of build_tiles, rows 4..6 in the substitution buffers -- all dead during the factorisation
-    DEV T *pfb(int t) const { return t < 4 ? dgs + 64 * t : x2 + 64 * (t - 4); }
-    // One block-step: every wave factors the 4x4 diagonal block (same data), solves the panel rows of ITS OWN tile rows against it, stores their
-    // L~ entries and publishes their fragments; after a barrier every wave picks up the fragments of the tile columns it needs and runs its
-    // trailing updates.  (Until round 3 every wave solved every tile row it needed a fragment of -- up to seven instead of two -- which made
-    // the block-step three times as long for wave 0 as the second barrier costs.)
+    // One block-step: every wave factors the 4x4 diagonal block (same data), solves the panel rows of ITS OWN tile rows against it (x L_dd^T = a), forms
+    // their L~ = x D^-1 = a A_jj^-1 entries, stores them in the factor image and runs its trailing updates in the form  K -= L~ A_.j^T  -- A fragment: its
+    // own L~ rows, B fragment: the RAW panel rows of the tile column, which every wave reads from the panel buffer.  Nothing a wave computes in a
+    // block-step is needed by another wave before the next panel: ONE workgroup barrier per block-step.  (Until round 4 the update was L L^T with
+    // L = A_.j L_dd^-T on both sides: the solved rows of the other waves' tile rows had to be published first -- a second barrier per block-step; 48 % of
+    // the wave lifetime was barrier / s_waitcnt wait.  L~ comes out of two triangular solves as before, so the update is as accurate as the factor image.)
+    DEV T raw_fragment(const T *pn, int t, int c, int kk, int jc) const   // component kk of raw panel row 16 t + c, negated, zero on dead rows
+    {
+        const int row = 16 * t + c;
+        const T v = pn[4 * row + kk];
+        return (row >= jc && row <= n) ? -v : (T)0;
+    }
     template <int W, int TC> DEV bool factor_column(acc_t (&k0)[Rows<W>::N0], acc_t (&k1)[Rows<W>::N1])
     {
         constexpr int R0 = Rows<W>::R0, R1 = Rows<W>::R1;
@@ -233,7 +238,7 @@ template <typename T, int N> struct WideSolver {
             const int jb = 4 * TC + s4, j0 = 4 * jb;
             const T *pn = pan + (jb & 1) * 4 * NP;
             const ipm::Diag4<T> dd = ipm::load_diag4(pn + 4 * j0);
-            // the panel rows of this wave's tile rows do not depend on the diagonal factor until the solve: request them now
+            // the panel rows of this wave's tile rows and the raw fragments of the tile columns it updates do not depend on the diagonal factor: request them now
             T av[2][4];
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
@@ -242,6 +247,10 @@ template <typename T, int N> struct WideSolver {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) av[o][k] = ar[k];
             }
+            const int jc = j0 + kk;
+            T bf[NTF];   // raw fragments of tile rows TC .. R0 (R1 < R0: a prefix of them serves the second tile row)
+#pragma unroll
+            for (int t = 0; t < NTF; ++t) bf[t] = (t >= TC && t <= R0) ? raw_fragment(pn, t, c, kk, jc) : (T)0;
             const ipm::Chol4<T> c4 = ipm::factor_diag4(dd);
             if (!c4.ok) return false;  // not positive definite (same data in every wave)
             if (tid == 0) c4.store_inv(sinvb + 16 * jb);
@@ -250,40 +259,36 @@ template <typename T, int N> struct WideSolver {
             const T c1 = kk == 0 ? c4.i10 : (kk == 1 ? c4.r1 : (T)0);
             const T c2 = kk == 0 ? c4.i20 : (kk == 1 ? c4.i21 : (kk == 2 ? c4.r2 : (T)0));
             const T c3 = kk == 0 ? c4.i30 : (kk == 1 ? c4.i31 : (kk == 2 ? c4.i32 : c4.r3));
-            const int jc = j0 + kk;
             T *colL = Lc + offc_rt(jc < n ? jc : 0);
             T own[2] = {(T)0, (T)0};
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
-                constexpr int dummy = 0; (void)dummy;
                 const int t = o == 0 ? R0 : R1;
                 if (t < TC) continue;                         // no second row (R1 = -1) / finished tile row: static after unrolling
                 const int row = 16 * t + c;
                 T x[4];
                 c4.solve_row(av[o], x);
-                const T xs = kk == 0 ? x[0] : (kk == 1 ? x[1] : (kk == 2 ? x[2] : x[3]));
+                const T lt = fma(x[3], c3, fma(x[2], c2, fma(x[1], c1, x[0] * c0)));   // component kk of L~ = L D^-1
                 const bool live = row >= jc && row <= n;
-                own[o] = live ? xs : (T)0;                    // component kk of L (fragment of the trailing update)
-                if (live) colL[row] = fma(x[3], c3, fma(x[2], c2, fma(x[1], c1, x[0] * c0)));  // component kk of L~ = L D^-1
-                pfb(t)[lane] = own[o];
+                own[o] = live ? lt : (T)0;                    // A fragment of the trailing update
+                if (live) colL[row] = lt;
             }
-            WGSYNC();   // the solved panel is published
             if (j0 + 4 < n) {
                 const bool same = s4 < 3;   // the next panel still lies in tile column TC (and that column still has live entries)
                 if constexpr (R0 >= TC) {
-                    if (same) { const T bt = TC == R0 ? own[0] : pfb(TC)[lane]; k0[TC] = Real<T>::mfma(own[0], -bt, k0[TC]); }
+                    if (same) k0[TC] = Real<T>::mfma(own[0], bf[TC], k0[TC]);
 #pragma unroll
-                    for (int t = TC + 1; t <= R0; ++t) { const T bt = t == R0 ? own[0] : pfb(t)[lane]; k0[t] = Real<T>::mfma(own[0], -bt, k0[t]); }
+                    for (int t = TC + 1; t <= R0; ++t) k0[t] = Real<T>::mfma(own[0], bf[t], k0[t]);
                 }
                 if constexpr (R1 >= TC) {
-                    if (same) { const T bt = TC == R1 ? own[1] : pfb(TC)[lane]; k1[TC] = Real<T>::mfma(own[1], -bt, k1[TC]); }
+                    if (same) k1[TC] = Real<T>::mfma(own[1], bf[TC], k1[TC]);
 #pragma unroll
-                    for (int t = TC + 1; t <= R1; ++t) { const T bt = t == R1 ? own[1] : pfb(t)[lane]; k1[t] = Real<T>::mfma(own[1], -bt, k1[t]); }
+                    for (int t = TC + 1; t <= R1; ++t) k1[t] = Real<T>::mfma(own[1], bf[t], k1[t]);
                 }
                 if (same) extract_panel<W, TC>(jb + 1, k0, k1);
                 else extract_panel<W, (TC + 1 < NTF ? TC + 1 : TC)>(jb + 1, k0, k1);
             }
-            WGSYNC();   // the next panel is complete (and the fragments have been read)
+            WGSYNC();   // the next panel is complete (and this one has been read)
         }
         return true;
     }
@@ -449,9 +454,10 @@ template <typename T, int N> struct WideSolver {
 // Workgroups per CU.  The workgroup is latency-bound between its barriers and the SIMDs' issue ports are mostly idle (tools/calib/issue_probe.hip), so
 // throughput follows the number of resident workgroups almost 1 : 1.  fp64 at N >= 40: 56 ... 74 KB of LDS allow two (256 VGPRs, no scratch); at
 // N = 32 / 36 the 44 / 50 KB allow three, which is worth the scratch that 168 VGPRs cost: 1.62 -> 2.14 and 1.39 -> 1.85 M solves/s at B = 262 144.
-// fp32: four (128 VGPRs), five up to N = 40 (+8 / +13 / +2 % at N = 32 / 36 / 40).
+// fp32: four (128 VGPRs), five up to N = 36 (+8 / +13 % at N = 32 / 36; N = 40 gained 2 % until round 4, when the raw fragments of the one-barrier block-step
+// raised its register pressure and the allocator put spill code ahead of an exec-mask restore: tools/spill_exec_check.py -- four, no scratch).
 template <typename T, int N>
-__global__ __launch_bounds__(256, sizeof(T) == 8 ? (N <= 36 ? 3 : 2) : (N <= 40 ? 5 : 4)) void kmpc_solve_wide_kernel(KP P, KIO<T> io)
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? (N <= 36 ? 3 : 2) : (N <= 36 ? 5 : 4)) void kmpc_solve_wide_kernel(KP P, KIO<T> io)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WideSolver<T, N>::lds_elems() * sizeof(T)];
     ipm::run_solver<WideSolver<T, N>>(P, io, smem);
