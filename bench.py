@@ -196,6 +196,34 @@ def closed_loop_latency(device, steps=150):
             "worst_status": worst}
 
 
+def dropin_host_path_latency(device, steps=400):
+    """The drop-in B = 1 path exactly as the reference's node drives it (mpc_cmd_pub.jl:115-141): HOST arrays through the module API mirror
+    (KinematicMPC.update_init_cond / update_reference / solve_model / update_current_input / get_solver_results -> kmpc_solve_batch_host), N = 8, warm-started,
+    a car accelerating along a straight reference.  Wall time of the whole control step, Python included.  Round 4: the host entry point runs small batches on
+    pinned, device-mapped host memory (no copy launches) and waits on a completion counter in that memory (174 -> 57 us at N = 8)."""
+    from mkz_mpc_path_follower_amd import KinematicMPC
+    k = KinematicMPC(N=8, device=device)
+    k.update_cost(9, 9, 10, 0, 100, 1000, 0, 0)     # mpc_cmd_pub.jl:49
+    N, lat, its, worst, x = 8, [], [], 0, 0.0
+    for i in range(steps):
+        v = min(15.0, 0.1 * i)
+        xr = x + v * 0.2 * np.arange(N + 1) + 0.3
+        t0 = time.perf_counter()
+        k.update_init_cond(x, 0.05 * np.sin(0.05 * i), 0.01, v)
+        k.update_reference(xr, np.zeros(N + 1), np.zeros(N + 1), v)
+        a, dsteer, st = k.solve_model()
+        k.update_current_input(dsteer, a)
+        k.get_solver_results()
+        lat.append(time.perf_counter() - t0); its.append(k.iters); worst = max(worst, 0 if st == "Optimal" else 1)
+        x += v * 0.1
+    k.close()
+    w = np.array(lat[50:]) * 1e6
+    return {"workload": "N=8, B=1, host arrays through the module-API mirror (kmpc_solve_batch_host), warm start, %d control steps" % steps,
+            "p50_step_us": float(np.percentile(w, 50)), "p99_step_us": float(np.percentile(w, 99)), "mean_iterations": float(np.mean(its[50:])), "worst_status": worst,
+            "note": "whole control step incl. Python; a near-empty kernel costs 18 us of launch + synchronisation on this stack and one iteration of a lone fp64 wave "
+                    "7-9 us (tools/latency_floor.py, DESIGN.md section 7)"}
+
+
 def closed_loop_fleet(device, B=4096, steps=40):
     """The same 10 Hz loop for a FLEET: B vehicles spread along the recorded path, each with its own warm start -- waypoint look-ahead, the N = 8
     solve (the reference's horizon) and the plant, all on the device.  Extra key: vehicle control steps per second and the solve's share."""
@@ -602,6 +630,7 @@ def main():
             res["p50_latency_us_B1"] = float(np.percentile(lat[10:], 50) * 1e6)
             res["closed_loop_N8"] = closed_loop_latency(local)
             res["config1_gpu_B1_cold"] = gpu_config1_latency(local)
+            res["dropin_host_path_N8"] = dropin_host_path_latency(local)
             if Bl == 4096 and N == 20 and a.dtype == "f64" and not a.quick:
                 # the headline cycles through K draws; the same workload over 8 OTHER seeded batches (launch time = slowest problem of the draw)
                 res["closed_loop_fleet_N8_B4096"] = closed_loop_fleet(local)

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,7 @@ hipError_t kmpc_launch_command(int, const double *, const int32_t *, uint8_t *, 
 template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, const T *, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
 
 #ifndef KMPC_QUAD_MIN_BATCH
+#define KMPC_HOST_ZERO_COPY_MAX 16   // kmpc_solve_batch_host: batches up to this size run on pinned host memory (no copies); above, staged through device memory
 #define KMPC_QUAD_MIN_BATCH 1024   // below this the one-wave-per-problem kernel's shorter single-solve latency wins (measured: tools/quad_probe.py)
 #endif
 
@@ -42,6 +44,11 @@ struct kmpc_handle {
     // staging for the host-pointer entry point
     void *dbuf;
     size_t dbuf_bytes;
+    // ... and for SMALL batches (B <= KMPC_HOST_ZERO_COPY_MAX: the reference's own B = 1 loop) one pinned, device-mapped host buffer the kernel reads its
+    // inputs from and writes its outputs to directly: no copy launches at all (round 4: 13 small pageable copies cost 120 us of a 174 us control step)
+    void *hbuf, *hbuf_dev;
+    size_t hbuf_bytes;
+    unsigned int *done_flag;   // device view of the completion counter inside hbuf while such a launch is being issued, else NULL
     // start-order workspace (kmpc_schedule.hip): perm[cap], tag[cap], hist[2][256]
     int32_t *perm;
     uint32_t *tag, *hist;
@@ -132,6 +139,9 @@ extern "C" int32_t kmpc_create(const kmpc_config *cfg, int32_t device, kmpc_hand
     h->device = device;
     h->dbuf = nullptr;
     h->dbuf_bytes = 0;
+    h->hbuf = h->hbuf_dev = nullptr;
+    h->hbuf_bytes = 0;
+    h->done_flag = nullptr;
     h->perm = nullptr; h->tag = nullptr; h->hist = nullptr; h->sched_cap = 0; h->sched_parity = 0;
     const double w0[8] = {9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0};  // MKZMPCPathFollower.jl:51-59
     const double w1[8] = {0.0, 9.0, 10.0, 0.5, 100.0, 1000.0, 0.0, 0.0};  // MKZMPCPathFollowerFrenet.jl:51-59 (no x slot)
@@ -150,6 +160,7 @@ extern "C" int32_t kmpc_destroy(kmpc_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->dbuf) (void)hipFree(h->dbuf);
+    if (h->hbuf) (void)hipHostFree(h->hbuf);
     if (h->perm) (void)hipFree(h->perm);
     if (h->tag) (void)hipFree(h->tag);
     if (h->hist) (void)hipFree(h->hist);
@@ -209,6 +220,7 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
     io.stamps = g_stamps;
     const KP P = make_kp(h, B, warm && warmU ? 1 : 0, -1);
     io.perm = nullptr;
+    io.done = h->done_flag;   // (set only around the small-batch host entry point's launch)
     // start order: only matters once a launch no longer fits on the chip at once (2 waves x 4 SIMDs x 256 CUs)
     if (h->cfg.model == 1) {  // Frenet functor: `ref` carries k_poly [B,4]; index order (the start-order key reads reference points)
         if (h->cfg.kernel_variant != 1 && kmpc_fast_available<T>(P.N)) HIPCHK(h, kmpc_launch_solve_fast_frenet<T>(P, io, st));
@@ -302,6 +314,53 @@ extern "C" int32_t kmpc_solve_batch_host(kmpc_handle *h, int32_t B, const void *
                            b * 2 * es, b * 4, b * es, b * es, b * 4, b * N * 2 * es, b * (N + 1) * 4 * es, 0};
     size_t off[13], total = 0;
     for (int i = 0; i < 13; ++i) { off[i] = total; total += (sz[i] + 255) & ~(size_t)255; }
+    hipStream_t st = h->stream;
+    if (B <= KMPC_HOST_ZERO_COPY_MAX) {
+        // small batch: the kernel works on pinned host memory (inputs: one burst of loads per problem when it starts; outputs: posted writes when it ends)
+        if (total > h->hbuf_bytes) {
+            if (h->hbuf) HIPCHK(h, hipHostFree(h->hbuf));
+            h->hbuf = h->hbuf_dev = nullptr; h->hbuf_bytes = 0;
+            size_t cap = 0;   // sized once for the largest zero-copy batch of this handle's horizon
+            { const size_t bb = KMPC_HOST_ZERO_COPY_MAX;
+              const size_t szm[12] = {bb * 4 * es, bb * (N + 1) * 3 * es, bb * es, bb * 2 * es, bb * N * 2 * es, bb * 2 * es, bb * 4, bb * es, bb * es, bb * 4, bb * N * 2 * es, bb * (N + 1) * 4 * es};
+              for (int i = 0; i < 12; ++i) cap += (szm[i] + 255) & ~(size_t)255; }
+            cap += 256;   // + the completion counter
+            HIPCHK(h, hipHostMalloc(&h->hbuf, cap, hipHostMallocMapped));
+            HIPCHK(h, hipHostGetDevicePointer(&h->hbuf_dev, h->hbuf, 0));
+            h->hbuf_bytes = cap;
+        }
+        char *hp = (char *)h->hbuf, *dp = (char *)h->hbuf_dev;
+        memcpy(hp + off[0], z0, sz[0]); memcpy(hp + off[1], ref, sz[1]); memcpy(hp + off[2], v_target, sz[2]); memcpy(hp + off[3], u_prev, sz[3]);
+        if (warm_U && warm) memcpy(hp + off[4], warm_U, sz[4]);
+        // completion: every problem adds 1 to a counter in the pinned buffer after its outputs (release, system scope); the host spins on it -- the runtime's
+        // own completion path (interrupt / signal wait) is several microseconds slower -- and falls back to the stream after 2 ms (long solves, stalled device)
+        volatile unsigned int *flag_h = (volatile unsigned int *)(hp + h->hbuf_bytes - 256);
+        *flag_h = 0u;
+        h->done_flag = (unsigned int *)(dp + h->hbuf_bytes - 256);
+        int rc = kmpc_solve_batch(h, B, dp + off[0], dp + off[1], dp + off[2], dp + off[3], warm_U ? dp + off[4] : nullptr, warm,
+                                  dp + off[5], (int32_t *)(dp + off[6]), dp + off[7], dp + off[8], (int32_t *)(dp + off[9]),
+                                  out_U ? dp + off[10] : nullptr, out_X ? dp + off[11] : nullptr, st);
+        h->done_flag = nullptr;
+        if (rc != KMPC_OK) return rc;
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            bool seen = false;
+            for (;;) {
+                if (__atomic_load_n((const unsigned int *)flag_h, __ATOMIC_ACQUIRE) >= (unsigned)B) { seen = true; break; }
+                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            }
+            if (!seen) HIPCHK(h, hipStreamSynchronize(st));
+        }
+        memcpy(out_u0, hp + off[5], sz[5]); memcpy(out_status, hp + off[6], sz[6]);
+        if (out_cost) memcpy(out_cost, hp + off[7], sz[7]);
+        if (out_viol) memcpy(out_viol, hp + off[8], sz[8]);
+        if (out_iters) memcpy(out_iters, hp + off[9], sz[9]);
+        if (out_U) memcpy(out_U, hp + off[10], sz[10]);
+        if (out_X) memcpy(out_X, hp + off[11], sz[11]);
+        if (warm_U) memcpy(warm_U, hp + off[4], sz[4]);
+        return KMPC_OK;
+    }
     if (total > h->dbuf_bytes) {
         if (h->dbuf) HIPCHK(h, hipFree(h->dbuf));
         h->dbuf = nullptr; h->dbuf_bytes = 0;
@@ -309,7 +368,6 @@ extern "C" int32_t kmpc_solve_batch_host(kmpc_handle *h, int32_t B, const void *
         h->dbuf_bytes = total;
     }
     char *d = (char *)h->dbuf;
-    hipStream_t st = h->stream;
     HIPCHK(h, hipMemcpyAsync(d + off[0], z0, sz[0], hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(d + off[1], ref, sz[1], hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(d + off[2], v_target, sz[2], hipMemcpyHostToDevice, st));

@@ -29,6 +29,7 @@ struct KIO {
     T *outU, *outX;
     unsigned long long *stamps;  // diagnostic builds only (KMPC_STAMPS), else NULL
     const int32_t *perm;         // start order: workgroup i solves problem perm[i] (NULL = index order)
+    unsigned int *done;          // host-visible completion counter (pinned memory) of the small-batch host entry point, else NULL: every problem adds 1 after its outputs
 };
 
 template <typename T>

@@ -1104,6 +1104,13 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
 #endif
         if (io.iters) io.iters[b] = iters;
     }
+    // small-batch host entry point (kmpc_solve_batch_host, B <= 16): the outputs above went to pinned host memory; the host spins on this counter instead
+    // of going through the runtime's completion path (launch + synchronisation of an EMPTY kernel cost 18 us of a 53 us warm solve)
+    if (io.done) {
+        __threadfence_system();
+        xsync<NTH>();
+        if (s.vid == 0) __hip_atomic_fetch_add(io.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace ipm

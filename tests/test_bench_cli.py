@@ -50,6 +50,8 @@ def test_bench_line_single_gpu():
     assert abs(c1["cold"]["cost"] - 15738.467) < 1e-2 and c1["cold"]["p50_us"] <= c1["cold"]["p99_us"] < c1["reference_cap_us"]
     g1 = d["config1_gpu_B1_cold"]
     assert g1["status"] == 0 and abs(g1["cost"] - 15738.467) < 1e-2 and g1["iterations"] == c1["cold"]["iterations"]
+    hp = d["dropin_host_path_N8"]   # the module-API mirror on host arrays: no copy launches since round 4 (174 us before)
+    assert hp["worst_status"] == 0 and hp["p50_step_us"] < 120 and hp["p50_step_us"] <= hp["p99_step_us"]
     assert d["parity_sample"]["unexplained"] == 0 and d["parity_sample"]["within_tol"] >= 4096 - 8
     assert "unavailable" in d["reference_julia_ipopt_baseline"] or "julia found" in d["reference_julia_ipopt_baseline"]
 
