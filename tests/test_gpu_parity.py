@@ -359,6 +359,34 @@ def test_warm_start_and_host_entry(oracle, N, B):
     assert np.abs(h["cost"] - c_cost.cpu().numpy()).max() <= 1e-9 * np.abs(h["cost"]).max()
 
 
+@pytest.mark.parametrize("N,dtype", [(8, np.float64), (20, np.float64), (50, np.float64), (20, np.float32)])
+def test_host_entry_small_batches_on_pinned_memory(N, dtype):
+    """kmpc_solve_batch_host runs batches of up to 16 problems on pinned, device-mapped HOST memory with a completion counter (round 4: no copy launches --
+    the reference's own B = 1 loop) and larger ones through staged device buffers: both must return bit-for-bit what the device-pointer entry point
+    returns, cold and warm-started (warm_U is read AND written back through the same path)."""
+    from mkz_mpc_path_follower_amd import BatchMPC
+    from mkz_mpc_path_follower_amd.solver import solve_host
+    d = make_batch(40, N, cfg_id=8, dtype=dtype)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    s = BatchMPC(N=N, dtype=tdt)
+    for B in (1, 3, 16, 17, 40):
+        sl = {k: d[k][:B] for k in ("z0", "ref", "v_target", "u_prev")}
+        W = torch.zeros((B, N, 2), dtype=tdt, device="cuda")
+        o = s.solve(sl["z0"], sl["ref"], sl["v_target"], sl["u_prev"], warm_U=W, warm=False, want_U=True, want_X=True)
+        torch.cuda.synchronize()
+        ref_ = {k: v.cpu().numpy().copy() for k, v in o.items()}
+        h = solve_host(N, sl["z0"], sl["ref"], sl["v_target"], sl["u_prev"], dtype=dtype)
+        for k in ("u0", "status", "cost", "viol", "iters", "U", "X"):
+            assert np.array_equal(h[k], ref_[k]), (B, k)
+        # warm start from a perturbed solution: the same problem through both entry points
+        W0 = (0.9 * ref_["U"]).astype(dtype)
+        Wd = torch.as_tensor(W0.copy(), device="cuda")
+        ow = s.solve(sl["z0"], sl["ref"], sl["v_target"], sl["u_prev"], warm_U=Wd, warm=True, want_U=True)
+        torch.cuda.synchronize()
+        hw = solve_host(N, sl["z0"], sl["ref"], sl["v_target"], sl["u_prev"], dtype=dtype, warm_U=W0)
+        assert np.array_equal(hw["U"], ow["U"].cpu().numpy()) and np.array_equal(hw["iters"], ow["iters"].cpu().numpy()) and (hw["status"] == 0).all()
+
+
 def test_kinematic_mpc_module_api_and_node_loop():
     """the six functions of MKZMPCPathFollower.jl:132-207 with the reference's argument orders, driven
     by the loop of mpc_cmd_pub.jl:86-157"""
