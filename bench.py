@@ -44,7 +44,7 @@ def algorithmic_flops_per_iteration(N):
     return 150 * N + 32 * N * N + f_cond + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
 
 
-def executed_flops_per_iteration(N):
+def executed_flops_per_iteration(N, kernel=""):
     # what the kernels execute since round 2: condensing by the O(N^2) adjoint recursion -- per stage and live column 5 FMAs to recover G_s,
     # 4 for the two Hessian rows, 2 for the second-order row, 5 for A^T p, 10 for W G (52 flops), columns 0..2s+1 live at stage s -- plus the
     # suffix scans of the terminal sensitivities (~40 N); linearisation and the IPM step as in SURVEY.md 8(d).  This is the numerator of
@@ -53,6 +53,8 @@ def executed_flops_per_iteration(N):
     # spare lanes; same 52 flops per live column and stage) and is stitched by one rank-4 product: 8 flops per entry of the 2M x 2M lower triangle.
     n, m = 2 * N, 10 * N - 4
     M = min(N // 2, (64 - n) // 2) if N <= 28 else N // 2   # kmpc_fast.hip / kmpc_wide.hip: MSPLIT
+    if "quad" in kernel or "frenet" in kernel:
+        M = 0                                                  # the four-per-wave kernel and the Frenet functor do not split the recursion (no stitch product)
     return 150 * N + 52 * N * (N + 1) + 40 * N + 8 * M * (2 * M + 1) + (n ** 3 / 3.0 + 4 * n * n + 10 * m)
 
 
@@ -154,7 +156,7 @@ def other_config(N, B, dtype, cfg_id, dev, local, steps=5, warmup=2):
     ms, out = time_launches(solver, din, steps, warmup)
     iters = out["iters"].float().mean().item()
     peak = FP64_PEAK_TFLOPS if dtype == "f64" else FP32_PEAK_TFLOPS
-    tf = executed_flops_per_iteration(N) * iters * B / (ms * 1e-3) / 1e12
+    tf = executed_flops_per_iteration(N, kernel_name(N, dtype, B)) * iters * B / (ms * 1e-3) / 1e12
     tf_model = algorithmic_flops_per_iteration(N) * iters * B / (ms * 1e-3) / 1e12
     es = 8 if dtype == "f64" else 4
     r = {"workload": "batch=%d, N=%d, %s, 1 GPU, seeded synthetic (cfg_id %d)" % (B, N, dtype, cfg_id), "solves_per_s": B / (ms * 1e-3),
