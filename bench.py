@@ -597,7 +597,7 @@ def main():
             # fp64 VALU ISSUE while the chip is full and by single-wave latency in the tail, not by the matrix cores; the denominator is the
             # fp64 vector = fp64 MFMA peak (78.6 TFLOP/s), the numerator the flops the kernel EXECUTES per launch (the SURVEY 8(d) model,
             # whose O(N^3) condensing term the kernels no longer run, is kept beside it as frac_survey_model so that rounds compare)
-            "roofline": {"bound": "valu", "bound_note": "fp64 VALU issue while the chip is full, single-wave latency in the tail; MFMA pipes ~5 % busy "
+            "roofline": {"bound": "valu", "bound_note": "fp64 VALU issue while the chip is full, single-wave latency in the tail; MFMA pipes ~5 %% busy "
                                                         "(%s); priced against the fp64 vector = MFMA peak" % ((counter_profile(kname) or {}).get("file", "profiles/")),
                          "achieved": ach_tf, "peak": peak, "unit": "TFLOP/s", "frac": ach_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": kern_ms, "launches_timed": a.steps,

@@ -24,7 +24,8 @@ def _assert_follows(traj, state, cmd, stop, status, what, overshoot=0.05):
     nl = sm["n_live"]
     assert nl >= 600 and (np.asarray(status)[:nl] == 0).all(), (what, np.bincount(np.asarray(status)[:nl]))
     assert sm["ect"][100:nl].max() < 0.5 and sm["ect"][:nl].max() < sm["ect"][0] + overshoot, (what, sm["ect"][100:nl].max(), sm["ect"][:nl].max())
-    assert sm["ect"][50:nl].max() < 0.3, (what, sm["ect"][50:nl].max())                      # measured 0.226
+    if overshoot <= 0.05:   # the launch file's own vehicle: measured 0.226 m after 5 s (a vehicle started 2 m / 0.5 rad off needs up to 8 s to come within 0.5 m)
+        assert sm["ect"][50:nl].max() < 0.3, (what, sm["ect"][50:nl].max())
     assert sm["max_dacc"] <= 0.15 + 1.5e-8 and sm["max_ddf"] <= 0.05 + 1.5e-8, (what, sm["max_dacc"], sm["max_ddf"])
     assert np.abs(cmd[:nl, 0]).max() <= 1.0 + 1.5e-8 and np.abs(cmd[:nl, 1]).max() <= 0.5 + 1.5e-8
     assert sm["t_stop"] is not None and 60.0 < sm["t_stop"] < 70.0 and np.asarray(stop)[nl:].all(), (what, sm["t_stop"])
