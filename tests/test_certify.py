@@ -368,6 +368,7 @@ def _certify_frenet(O, N, z0, kp, vt, up, U, idx, relax=1e-8):
 @pytest.mark.gpu
 @pytest.mark.parametrize("what,N,B,f32,kw", [
     ("wide<float,32>", 32, 512, True, {}), ("wide<float,36>", 36, 512, True, {}), ("wide<float,40>", 40, 512, True, {}),
+    ("wide<float,48>", 48, 512, True, {}), ("wide<float,50>", 50, 512, True, {}),   # (40 B of scratch each since the one-barrier block-step of round 4)
     ("quad<float>", 8, 1024, True, {}), ("dense<float,12>", 12, 2560, True, {}), ("dense<float,8>", 8, 2560, True, dict(kernel_variant=2)),
     ("dense<double,8>", 8, 2560, False, dict(kernel_variant=2)),
     ("frenet<double,24>", 24, 512, False, dict(model=1)), ("frenet<float,16>", 16, 512, True, dict(model=1)), ("frenet<float,20>", 20, 512, True, dict(model=1)),

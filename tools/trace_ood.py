@@ -8,9 +8,10 @@ _lib.LIB_PATH = os.path.join(ROOT, "mkz_mpc_path_follower_amd", "libkmpc_hip_tra
 from mkz_mpc_path_follower_amd import BatchMPC
 from mkz_mpc_path_follower_amd.synthetic import make_ood_batch
 N, b = int(sys.argv[1]), int(sys.argv[2])
+F32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
 paths = [dict(np.load(os.path.join(ROOT, "tests", "golden", "path%d_decimated.npz" % k))) for k in (1, 2, 3)]
 d = make_ood_batch(262144, N, seed=4100 + N, paths=paths)
-s = BatchMPC(N=N, dtype=torch.float64)
+s = BatchMPC(N=N, dtype=torch.float32 if F32 else torch.float64)
 L = _lib.load()
 tr = torch.zeros((256, 8), dtype=torch.float64, device="cuda")
 L.kmpc_debug_set_stamps.argtypes = [C.c_void_p]
