@@ -145,28 +145,40 @@ def two_in_flight(N, B, tdt, din, local, steps=40, warmup=6):
             "note": "extra key, not the headline: consecutive independent batches overlapped on two streams"}
 
 
-def other_config(N, B, dtype, cfg_id, dev, local, steps=5, warmup=2):
-    """untimed-headline extra key: one of the other BASELINE configs on this GPU (kernel time by HIP events over resident inputs)"""
+def other_config(N, B, dtype, cfg_id, dev, local, steps=5, warmup=2, packed=False):
+    """untimed-headline extra key: one of the other BASELINE configs on this GPU (kernel time by HIP events over resident inputs);
+    packed = True: the same problems through kmpc_solve_batch_packed (ABI v8: one 64-B-aligned record per problem)"""
     from mkz_mpc_path_follower_amd import BatchMPC
     from mkz_mpc_path_follower_amd.synthetic import make_batch
     tdt = torch.float64 if dtype == "f64" else torch.float32
     d = make_batch(B, N, cfg_id=cfg_id)
     din = {k: torch.as_tensor(d[k], dtype=tdt, device=dev) for k in ("z0", "ref", "v_target", "u_prev")}
     solver = BatchMPC(N=N, dtype=tdt, device=local)
-    ms, out = time_launches(solver, din, steps, warmup)
+    if packed:
+        rec = solver.pack(din["z0"], din["ref"], din["v_target"], din["u_prev"])
+
+        class _P:   # time_launches calls solver.solve(z0, ref, v_target, u_prev, out=...)
+            @staticmethod
+            def solve(z0, ref, vt, up, out=None):
+                return solver.solve_packed(rec, out=out)
+        ms, out = time_launches(_P, din, steps, warmup)
+    else:
+        ms, out = time_launches(solver, din, steps, warmup)
     iters = out["iters"].float().mean().item()
     peak = FP64_PEAK_TFLOPS if dtype == "f64" else FP32_PEAK_TFLOPS
     tf = executed_flops_per_iteration(N, kernel_name(N, dtype, B)) * iters * B / (ms * 1e-3) / 1e12
     tf_model = algorithmic_flops_per_iteration(N) * iters * B / (ms * 1e-3) / 1e12
     es = 8 if dtype == "f64" else 4
-    r = {"workload": "batch=%d, N=%d, %s, 1 GPU, seeded synthetic (cfg_id %d)" % (B, N, dtype, cfg_id), "solves_per_s": B / (ms * 1e-3),
+    r = {"workload": "batch=%d, N=%d, %s, 1 GPU, seeded synthetic (cfg_id %d)%s" % (B, N, dtype, cfg_id, ", packed records (kmpc_solve_batch_packed)" if packed else ""), "solves_per_s": B / (ms * 1e-3),
          "kernel": kernel_name(N, dtype, B), "kernel_ms": ms, "launches": steps, "mean_iterations": iters, "max_iterations": int(out["iters"].max().item()),
          "optimal_fraction": float((out["status"] == 0).float().mean().item()),
          "achieved_tflops": tf, "peak_tflops": peak, "frac_of_peak": tf / peak, "frac_survey_model": tf_model / peak,
          "flops_note": "frac_of_peak prices the flops the kernel executes (O(N^2) adjoint condensing); frac_survey_model the SURVEY 8(d) formula",
          "hbm_gbs_algorithmic": algorithmic_bytes_per_solve(N, es) * B / (ms * 1e-3) / 1e9}
-    k = counter_profile(r["kernel"])
+    k = counter_profile(r["kernel"] + (" packed records" if packed else ""))
     if k and k.get("hbm_bytes_per_dispatch") and k.get("batch") == B:
+        r["hbm_bytes_per_dispatch_counters"] = float(k["hbm_bytes_per_dispatch"])
+        r["hbm_traffic_over_algorithmic"] = float(k["hbm_bytes_per_dispatch"]) / (algorithmic_bytes_per_solve(N, es) * B)
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same kernel at the same batch (committed; corrected as MI355X_MICROARCH.md prescribes)
         r["hbm_gbs_counters"] = float(k["hbm_bytes_per_dispatch"]) / (ms * 1e-3) / 1e9
         r["hbm_frac_of_peak_counters"] = r["hbm_gbs_counters"] / HBM_PEAK_GBS
@@ -640,6 +652,8 @@ def main():
                 res["two_batches_in_flight"] = two_in_flight(N, Bl, tdt, din, local)
                 # the other single-GPU BASELINE configs, untimed-headline extra keys: configs[2] (fp32, B = 262144) and configs[4] (N = 50)
                 res["config3_fp32_B262144"] = other_config(20, 262144, "f32", 3, dev, local, steps=5, warmup=2)
+                # ... and through the packed-record entry point (ABI v8): same kernel, same results, whole-line fetches behind the start-order permutation
+                res["config3_fp32_B262144_packed"] = other_config(20, 262144, "f32", 3, dev, local, steps=5, warmup=2, packed=True)
                 res["config5_N50_B4096"] = other_config(50, 4096, "f64", 5, dev, local, steps=5, warmup=2)
                 # the shard one GPU of configs[3] (2 097 152 problems over 8 GPUs) gets, fp64
                 res["config4_shard_fp64_B262144"] = other_config(20, 262144, "f64", 4, dev, local, steps=3, warmup=1)

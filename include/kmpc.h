@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KMPC_ABI_VERSION 7
+#define KMPC_ABI_VERSION 8
 
 /* per-problem status, replaces the Symbol returned by solve_model() (MKZMPCPathFollower.jl:176,182) */
 enum {
@@ -144,6 +144,25 @@ int32_t kmpc_solve_batch(kmpc_handle *h, int32_t B, const void *z0, const void *
 int32_t kmpc_solve_batch_frenet(kmpc_handle *h, int32_t B, const void *z0, const void *k_poly, const void *v_target,
                                 const void *u_prev, void *warm_U, int32_t warm, void *out_u0, int32_t *out_status,
                                 void *out_cost, void *out_viol, int32_t *out_iters, void *out_U, void *out_X, void *stream);
+
+/* ---- packed records (ABI v8) -----------------------------------------------------------------------------------------
+ * The same hot path on ONE 64-byte-aligned input record and ONE 64-byte output record per problem instead of four input and five output
+ * arrays: with the start-order permutation adjacent workgroups read non-adjacent problems, and 8 ... 32-byte entries of separate arrays are
+ * fetched as whole lines (counter traffic 3.3 x the algorithmic bytes at B = 262 144, fp32; 2.1 x with records); a record is a whole number of 64-byte lines.
+ *   input record (scalars of the handle's dtype):  [0..3] z0 = x, y, psi, v   (update_init_cond, MKZMPCPathFollower.jl:132-138)
+ *                                                  [4]    v_target           (update_reference's v_des, :142-147)
+ *                                                  [5..6] u_prev = acc, d_f  (update_current_input, :151-154; accel first)
+ *                                                  [7]    unused
+ *                                                  [8 + 3 k + (0, 1, 2)] x_ref, y_ref, psi_ref of stage k = 0..N  (update_reference)
+ *                                                  zero padding up to kmpc_record_bytes(N, dtype)
+ *   output record (64 bytes):  u0 = (acc_opt[1], d_f_opt[1]) (solve_model, :179-182), cost, viol (scalars of the dtype), then status and iters (int32).
+ * warm_U / out_U / out_X as in kmpc_solve_batch (optional).  Results are bit-identical to kmpc_solve_batch on the same problems. */
+int64_t kmpc_record_bytes(int32_t N, int32_t dtype);   /* stride of the input records in bytes (a multiple of 64), -1 for bad arguments */
+/* device kernel: the four arrays of kmpc_solve_batch -> packed input records (for callers that hold the arrays) */
+int32_t kmpc_pack_records(kmpc_handle *h, int32_t B, const void *z0, const void *ref, const void *v_target, const void *u_prev,
+                          void *records, void *stream);
+int32_t kmpc_solve_batch_packed(kmpc_handle *h, int32_t B, const void *records, void *warm_U, int32_t warm, void *out_records,
+                                void *out_U, void *out_X, void *stream);
 
 /* Same with HOST pointers: copies in, solves, copies out, synchronises.  This is the form the
  * reference's single-problem API (B = 1) maps onto.  Batches of up to 16 problems run on a pinned, device-mapped host buffer of the

@@ -30,7 +30,8 @@ EXPORTS = ["kmpc_abi_version", "kmpc_config_default", "kmpc_create", "kmpc_destr
            "kmpc_get_cost", "kmpc_solve_batch", "kmpc_solve_batch_host", "kmpc_last_error",
            "kmpc_debug_condense", "kmpc_debug_mfma_probe",
            "kmpc_path_create", "kmpc_path_destroy", "kmpc_waypoints_batch", "kmpc_path_last_error",
-           "kmpc_sim_advance_batch", "kmpc_solve_batch_frenet", "kmpc_debug_kkt", "kmpc_command_batch"]
+           "kmpc_sim_advance_batch", "kmpc_solve_batch_frenet", "kmpc_debug_kkt", "kmpc_command_batch",
+           "kmpc_record_bytes", "kmpc_pack_records", "kmpc_solve_batch_packed"]
 
 _lib = None
 
@@ -68,6 +69,10 @@ def load():
     L.kmpc_path_last_error.restype = C.c_char_p
     L.kmpc_sim_advance_batch.argtypes = [i32, i32, vp, vp, i32, vp]
     L.kmpc_command_batch.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
+    L.kmpc_record_bytes.argtypes = [i32, i32]
+    L.kmpc_record_bytes.restype = C.c_int64
+    L.kmpc_pack_records.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    L.kmpc_solve_batch_packed.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

@@ -28,7 +28,8 @@ template <typename T> hipError_t kmpc_launch_fast_kkt(const KP &, const KDbgK<T>
 template <typename T> hipError_t kmpc_launch_wide_kkt(const KP &, const KDbgK<T> &, hipStream_t);
 hipError_t kmpc_launch_sim(int, double *, const double *, int, hipStream_t);
 hipError_t kmpc_launch_command(int, const double *, const int32_t *, uint8_t *, double *, double *, hipStream_t);
-template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, const T *, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
+template <typename T> hipError_t kmpc_launch_schedule(int, int, double, const T *, size_t, const T *, size_t, uint32_t *, uint32_t *, uint32_t *, int32_t *, hipStream_t);
+template <typename T> hipError_t kmpc_launch_pack(int, int, int, const T *, const T *, const T *, const T *, T *, hipStream_t);
 
 #ifndef KMPC_QUAD_MIN_BATCH
 #define KMPC_HOST_ZERO_COPY_MAX 16   // kmpc_solve_batch_host: batches up to this size run on pinned host memory (no copies); above, staged through device memory
@@ -208,12 +209,28 @@ static KP make_kp(const kmpc_handle *h, int B, int warm, int hessian_override)
     return P;
 }
 
+// input record of kmpc_solve_batch_packed in scalars: z0[4], v_target, u_prev[2], pad, ref[(N+1)*3], rounded up to whole 64-B lines (72 scalars
+// = 576 B at N = 20, fp64).  (Whole 128-B lines were measured too: same counter traffic, more padding -- profiles/README.md, round 4.)
+static inline int record_scalars(int N, int dtype)
+{
+    const int per_line = dtype == KMPC_F64 ? 8 : 16;
+    return (8 + 3 * (N + 1) + per_line - 1) / per_line * per_line;
+}
+
 template <typename T>
 static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, const void *vt, const void *up,
                      void *warmU, int warm, void *u0, int32_t *status, void *cost, void *viol, int32_t *iters,
-                     void *outU, void *outX, hipStream_t st)
+                     void *outU, void *outX, hipStream_t st, const void *rec = nullptr, void *orec = nullptr)
 {
     KIO<T> io;
+    const int rstride = record_scalars(h->cfg.N, h->cfg.dtype), per = (int)(64 / sizeof(T));
+    io.zs = 4; io.rs = h->cfg.model == 1 ? 4 : 3 * (h->cfg.N + 1); io.vs = 1; io.us = 2; io.u0s = 2; io.ss = 1; io.is = 1;
+    if (rec) {   // packed records: the same pointers aim into the records, every stride is the record's
+        z0 = rec; ref = (const T *)rec + 8; vt = (const T *)rec + 4; up = (const T *)rec + 5;
+        io.zs = io.rs = io.vs = io.us = rstride;
+        u0 = orec; cost = (T *)orec + 2; viol = (T *)orec + 3; status = (int32_t *)((T *)orec + 4); iters = status + 1;
+        io.u0s = io.ss = per; io.is = 16;
+    }
     io.z0 = (const T *)z0; io.ref = (const T *)ref; io.vt = (const T *)vt; io.up = (const T *)up;
     io.warmU = (T *)warmU; io.u0 = (T *)u0; io.status = status; io.cost = (T *)cost; io.viol = (T *)viol;
     io.iters = iters; io.outU = (T *)outU; io.outX = (T *)outX;
@@ -243,7 +260,7 @@ static int solve_dev(kmpc_handle *h, int B, const void *z0, const void *ref, con
             h->sched_parity = 0;
         }
         uint32_t *hc = h->hist + 256 * (h->sched_parity & 1), *hn = h->hist + 256 * ((h->sched_parity & 1) ^ 1);
-        HIPCHK(h, kmpc_launch_schedule<T>(B, P.N, P.dt, io.z0, io.ref, hc, hn, h->tag, h->perm, st));
+        HIPCHK(h, kmpc_launch_schedule<T>(B, P.N, P.dt, io.z0, (size_t)io.zs, io.ref, (size_t)io.rs, hc, hn, h->tag, h->perm, st));
         h->sched_parity ^= 1;
         io.perm = h->perm;
     }
@@ -273,6 +290,45 @@ extern "C" int32_t kmpc_solve_batch(kmpc_handle *h, int32_t B, const void *z0, c
                                  out_iters, out_U, out_X, st);
     return solve_dev<float>(h, B, z0, ref, v_target, u_prev, warm_U, warm, out_u0, out_status, out_cost, out_viol,
                             out_iters, out_U, out_X, st);
+}
+
+extern "C" int64_t kmpc_record_bytes(int32_t N, int32_t dtype)
+{
+    if (N < 2 || N > 56 || (dtype != KMPC_F64 && dtype != KMPC_F32)) return -1;
+    return (int64_t)record_scalars(N, dtype) * (dtype == KMPC_F64 ? 8 : 4);
+}
+
+extern "C" int32_t kmpc_pack_records(kmpc_handle *h, int32_t B, const void *z0, const void *ref, const void *v_target, const void *u_prev,
+                                     void *records, void *stream)
+{
+    if (!h) return KMPC_ERR_ARG;
+    if (B < 0) return fail(h, KMPC_ERR_ARG, "kmpc_pack_records: B=%d", B);
+    if (B == 0) return KMPC_OK;
+    if (!z0 || !ref || !v_target || !u_prev || !records) return fail(h, KMPC_ERR_ARG, "kmpc_pack_records: null buffer");
+    if (h->cfg.model != 0) return fail(h, KMPC_ERR_ARG, "kmpc_pack_records: Cartesian model only");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int stride = record_scalars(h->cfg.N, h->cfg.dtype);
+    if (h->cfg.dtype == KMPC_F64)
+        HIPCHK(h, kmpc_launch_pack<double>(B, h->cfg.N, stride, (const double *)z0, (const double *)ref, (const double *)v_target, (const double *)u_prev, (double *)records, (hipStream_t)stream));
+    else
+        HIPCHK(h, kmpc_launch_pack<float>(B, h->cfg.N, stride, (const float *)z0, (const float *)ref, (const float *)v_target, (const float *)u_prev, (float *)records, (hipStream_t)stream));
+    return KMPC_OK;
+}
+
+extern "C" int32_t kmpc_solve_batch_packed(kmpc_handle *h, int32_t B, const void *records, void *warm_U, int32_t warm, void *out_records,
+                                           void *out_U, void *out_X, void *stream)
+{
+    if (!h) return KMPC_ERR_ARG;
+    if (B < 0) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_packed: B=%d", B);
+    if (B == 0) return KMPC_OK;
+    if (!records || !out_records) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_packed: null required buffer");
+    if (((uintptr_t)records | (uintptr_t)out_records) & 63) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_packed: records must be 64-byte aligned");
+    if (h->cfg.model != 0) return fail(h, KMPC_ERR_ARG, "kmpc_solve_batch_packed: Cartesian model only");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->cfg.dtype == KMPC_F64)
+        return solve_dev<double>(h, B, nullptr, nullptr, nullptr, nullptr, warm_U, warm, nullptr, nullptr, nullptr, nullptr, nullptr, out_U, out_X, st, records, out_records);
+    return solve_dev<float>(h, B, nullptr, nullptr, nullptr, nullptr, warm_U, warm, nullptr, nullptr, nullptr, nullptr, nullptr, out_U, out_X, st, records, out_records);
 }
 
 extern "C" int32_t kmpc_solve_batch_frenet(kmpc_handle *h, int32_t B, const void *z0, const void *k_poly, const void *v_target,

@@ -29,6 +29,11 @@ struct KIO {
     T *outU, *outX;
     unsigned long long *stamps;  // diagnostic builds only (KMPC_STAMPS), else NULL
     const int32_t *perm;         // start order: workgroup i solves problem perm[i] (NULL = index order)
+    // element strides of the per-problem entries (ABI v8): the plain arrays of kmpc_solve_batch have (4, 3 (N + 1), 1, 2 | 2, 1, 1); with packed records
+    // (kmpc_solve_batch_packed) the same pointers aim INTO the records -- z0 = rec, vt = rec + 4, up = rec + 5, ref = rec + 8; u0 = orec,
+    // cost = orec + 2, viol = orec + 3, status / iters = the two int32 behind them -- and every stride is the record's (whole 64-B lines): no second code path
+    int zs, rs, vs, us;      // inputs: z0, ref, v_target, u_prev
+    int u0s, ss, is;         // outputs: u0, cost / viol, status / iters
     unsigned int *done;          // host-visible completion counter (pinned memory) of the small-batch host entry point, else NULL: every problem adds 1 after its outputs
 };
 

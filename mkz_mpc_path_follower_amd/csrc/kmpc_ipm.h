@@ -578,6 +578,12 @@ template <class SV> DEV void kkt_diag_staging(SV &s, typename SV::real sc, typen
     xsync<SV::NTH>();
 }
 
+// inputs of problem b through the element strides of KIO (plain arrays or packed records: kmpc_device.h)
+template <class SV> DEV void load_problem_io(SV &sv, const KIO<typename SV::real> &io, int b)
+{
+    sv.load_problem(io.z0 + (size_t)b * io.zs, io.ref + (size_t)b * io.rs, io.vt + (size_t)b * io.vs, io.up + (size_t)b * io.us, 0);
+}
+
 // body of a solve kernel: one problem per workgroup, start order through io.perm
 template <class SV> DEV void run_solver(const KP &P, const KIO<typename SV::real> &io, unsigned char *smem)
 {
@@ -589,7 +595,7 @@ template <class SV> DEV void run_solver(const KP &P, const KIO<typename SV::real
     __syncthreads();
 #endif
     SV sv(P, smem);
-    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
+    load_problem_io(sv, io, b);
     sv.solve(io, b);
 }
 
@@ -1085,7 +1091,7 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
         if (j < n) {
             if (io.outU) io.outU[(size_t)b * n + j] = U[i];
             if (io.warmU) io.warmU[(size_t)b * n + j] = U[i];
-            if (j < 2) io.u0[(size_t)b * 2 + j] = U[i];
+            if (j < 2) io.u0[(size_t)b * io.u0s + j] = U[i];
         }
     }
     if (io.outX && s.vid <= N) {
@@ -1095,14 +1101,13 @@ template <class SV> DEV void solve(SV &s, const KIO<typename SV::real> &io, int 
     STAMP_AT(s, 11);
     STAMP_OUT_AT(s, io.stamps, b);
     if (s.vid == 0) {
-        io.status[b] = status;
-        if (io.cost) io.cost[b] = Jt;
 #ifdef KMPC_DRIFT_PROBE
-        if (io.viol) io.viol[b] = drift_probe;
-#else
-        if (io.viol) io.viol[b] = viol;
+        viol = drift_probe;
 #endif
-        if (io.iters) io.iters[b] = iters;
+        io.status[(size_t)b * io.is] = status;
+        if (io.cost) io.cost[(size_t)b * io.ss] = Jt;
+        if (io.viol) io.viol[(size_t)b * io.ss] = viol;
+        if (io.iters) io.iters[(size_t)b * io.is] = iters;
     }
     // small-batch host entry point (kmpc_solve_batch_host, B <= 16): the outputs above went to pinned host memory; the host spins on this counter instead
     // of going through the runtime's completion path (launch + synchronisation of an EMPTY kernel cost 18 us of a 53 us warm solve)

@@ -970,7 +970,7 @@ __global__ __launch_bounds__(64) void kmpc_solve_kernel(KP P, KIO<T> io)
 #endif
     T scalars[16], params[32];
     Solver<T, NT> sv(P, smem, scalars, params);
-    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
+    ipm::load_problem_io(sv, io, b);
     sv.solve(io, b);
 }
 

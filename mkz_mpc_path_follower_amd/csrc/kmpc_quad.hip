@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? 2 : 4) void kmpc_solve_quad_ke
     __syncthreads();
 #endif
     QuadSolver<T> sv(P, smem);
-    sv.load_problem(io.z0, io.ref, io.vt, io.up, b);
+    ipm::load_problem_io(sv, io, b);
     sv.solve(io, b);
 }
 

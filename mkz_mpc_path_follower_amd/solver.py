@@ -130,6 +130,53 @@ class BatchMPC:
         highest degree first; X[B,N+1,4] = (s, e_y, e_psi, v).  Otherwise as solve()."""
         return self._solve(self.lib.kmpc_solve_batch_frenet, z0, k_poly, (4,), v_target, u_prev, warm_U, warm, want_U, want_X, out)
 
+    # ---- packed records (ABI v8, kmpc_solve_batch_packed; include/kmpc.h) -------------------------
+    def record_scalars(self):
+        """scalars per input record (kmpc_record_bytes / element size): z0[4], v_target, u_prev[2], pad, ref[(N+1)*3], zero padding to whole 64-B lines"""
+        return int(self.lib.kmpc_record_bytes(self.N, self.cfg.dtype)) // self.dtype.itemsize
+
+    def pack(self, z0, ref, v_target, u_prev, out=None):
+        """the four input arrays of solve() -> records [B, record_scalars()] (device kernel kmpc_pack_records)"""
+        z0 = self._dev(z0, (len(z0), 4))
+        B = z0.shape[0]
+        ref = self._dev(ref, (B, self.N + 1, 3))
+        v_target = self._dev(v_target, (B,))
+        u_prev = self._dev(u_prev, (B, 2))
+        rs = self.record_scalars()
+        rec = out if (out is not None and tuple(out.shape) == (B, rs) and out.dtype == self.dtype and out.device == self.device) else \
+            torch.empty((B, rs), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.kmpc_pack_records(self.h, B, _ptr(z0), _ptr(ref), _ptr(v_target), _ptr(u_prev), _ptr(rec),
+                                              C.c_void_p(_raw_stream(self.device.index))), self.h)
+        return rec
+
+    def solve_packed(self, records, warm_U=None, warm=False, want_U=False, want_X=False, out=None):
+        """records [B, record_scalars()] -> dict with `orec` (the [B, 64 bytes] output records) and views into it: u0 [B,2], cost [B], viol [B] (strided views),
+        status [B], iters [B] (int32 views); U / X as in solve().  Asynchronous on torch's current stream."""
+        N, rs = self.N, self.record_scalars()
+        if not (records.dtype == self.dtype and records.device == self.device and records.is_contiguous() and records.dim() == 2 and records.shape[1] == rs):
+            raise ValueError("records: expected a contiguous [B, %d] %s tensor on %s" % (rs, self.dtype, self.device))
+        B = records.shape[0]
+        per = 64 // self.dtype.itemsize
+        o = out if (out is not None and out.get("orec") is not None and tuple(out["orec"].shape) == (B, per)) else {}
+        if "orec" not in o:
+            o["orec"] = torch.zeros((B, per), dtype=self.dtype, device=self.device)
+            o["u0"], o["cost"], o["viol"] = o["orec"][:, 0:2], o["orec"][:, 2], o["orec"][:, 3]
+            ints = o["orec"].view(torch.int32).view(B, 64 // 4)
+            k = 4 * self.dtype.itemsize // 4
+            o["status"], o["iters"] = ints[:, k], ints[:, k + 1]
+        if want_U and o.get("U") is None:
+            o["U"] = torch.empty((B, N, 2), dtype=self.dtype, device=self.device)
+        if want_X and o.get("X") is None:
+            o["X"] = torch.empty((B, N + 1, 4), dtype=self.dtype, device=self.device)
+        if warm_U is not None:
+            warm_U = self._dev(warm_U, (B, N, 2))
+        _lib.check(self.lib.kmpc_solve_batch_packed(self.h, B, _ptr(records), _ptr(warm_U), 1 if (warm and warm_U is not None) else 0, _ptr(o["orec"]),
+                                                    _ptr(o["U"]) if want_U else None, _ptr(o["X"]) if want_X else None,
+                                                    C.c_void_p(_raw_stream(self.device.index))), self.h)
+        if warm_U is not None:
+            o["warm_U"] = warm_U
+        return o
+
     # ---- diagnostics for tests ------------------------------------------------------------------
     def debug_condense(self, z0, ref, v_target, U, hessian=1):
         N = self.N

@@ -23,7 +23,9 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libkmpc_hip.so does not export %s" % n
     assert sorted(_lib.EXPORTS) == names
-    assert L.kmpc_abi_version() == 7
+    assert L.kmpc_abi_version() == 8
+    assert L.kmpc_record_bytes(20, _lib.KMPC_F64) == 576 and L.kmpc_record_bytes(20, _lib.KMPC_F32) == 320 and L.kmpc_record_bytes(8, _lib.KMPC_F64) == 320   # 72 scalars at N = 20
+    assert L.kmpc_record_bytes(100, _lib.KMPC_F64) == -1
 
 
 def test_config_defaults_are_the_reference_constants():

@@ -40,6 +40,8 @@ def test_bench_line_single_gpu():
     for key, kern_peak in (("config3_fp32_B262144", 157.3), ("config5_N50_B4096", 78.6), ("config4_shard_fp64_B262144", 78.6), ("N8_fp64_B262144", 78.6)):
         c = d[key]
         assert c["optimal_fraction"] == 1.0 and c["peak_tflops"] == kern_peak and 0 < c["frac_of_peak"] < c["frac_survey_model"] < 1 and c["solves_per_s"] > 0
+    pk = d["config3_fp32_B262144_packed"]   # ABI v8: same kernel on packed records -- same iterations, no slower (measured equal), less counter traffic where committed
+    assert pk["optimal_fraction"] == 1.0 and pk["mean_iterations"] == d["config3_fp32_B262144"]["mean_iterations"] and pk["solves_per_s"] >= 0.93 * d["config3_fp32_B262144"]["solves_per_s"]
     assert d["config3_fp32_B262144"]["kernel"] == "kmpc_solve_fast_kernel<float,20>" and d["config5_N50_B4096"]["kernel"] == "kmpc_solve_wide_kernel<double,50>"
     assert d["config5_N50_B4096"]["solves_per_s"] >= 4e5
     assert d["N8_fp64_B262144"]["kernel"] == "kmpc_solve_quad_kernel<double>" and d["N8_fp64_B262144"]["solves_per_s"] >= 4e7

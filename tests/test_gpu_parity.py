@@ -387,6 +387,34 @@ def test_host_entry_small_batches_on_pinned_memory(N, dtype):
         assert np.array_equal(hw["U"], ow["U"].cpu().numpy()) and np.array_equal(hw["iters"], ow["iters"].cpu().numpy()) and (hw["status"] == 0).all()
 
 
+@pytest.mark.parametrize("N,B,dtype,kv", [(8, 2048, np.float64, 0), (8, 300, np.float64, 0), (20, 4096, np.float64, 0), (20, 4096, np.float32, 0), (50, 256, np.float64, 0),
+                                          (12, 3000, np.float32, 0), (13, 128, np.float64, 0)])
+def test_packed_records_entry_point(N, B, dtype, kv):
+    """ABI v8: kmpc_pack_records + kmpc_solve_batch_packed -- one 64-byte-aligned input record and one 64-byte output record per problem --
+    return bit for bit what kmpc_solve_batch returns on the four input arrays, in every kernel family (four per wave, one wave, four waves, generic) and with
+    the start-order pre-pass reading the records (B > 2048); warm starts included."""
+    from mkz_mpc_path_follower_amd import BatchMPC
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    d = make_batch(B, N, cfg_id=12, dtype=dtype)
+    s = BatchMPC(N=N, dtype=tdt, kernel_variant=kv)
+    a = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"], want_U=True, want_X=True)
+    rec = s.pack(d["z0"], d["ref"], d["v_target"], d["u_prev"])
+    assert rec.shape == (B, s.record_scalars()) and (s.record_scalars() * rec.element_size()) % 64 == 0 and rec.data_ptr() % 64 == 0
+    r = rec.cpu().numpy()
+    assert np.array_equal(r[:, 0:4], d["z0"]) and np.array_equal(r[:, 4], d["v_target"]) and np.array_equal(r[:, 5:7], d["u_prev"])
+    assert np.array_equal(r[:, 8:8 + 3 * (N + 1)].reshape(B, N + 1, 3), d["ref"]) and (r[:, 7] == 0).all() and (r[:, 8 + 3 * (N + 1):] == 0).all()
+    b = s.solve_packed(rec, want_U=True, want_X=True)
+    torch.cuda.synchronize()
+    for k in ("u0", "cost", "viol", "status", "iters", "U", "X"):
+        assert torch.equal(a[k], b[k].contiguous()), k
+    assert (a["status"] == 0).all()
+    W = (0.9 * a["U"]).clone()
+    aw = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"], warm_U=W.clone(), warm=True)
+    bw = s.solve_packed(rec, warm_U=W.clone(), warm=True)
+    torch.cuda.synchronize()
+    assert torch.equal(aw["u0"], bw["u0"].contiguous()) and torch.equal(aw["iters"], bw["iters"].contiguous()) and torch.equal(aw["warm_U"], bw["warm_U"])
+
+
 def test_kinematic_mpc_module_api_and_node_loop():
     """the six functions of MKZMPCPathFollower.jl:132-207 with the reference's argument orders, driven
     by the loop of mpc_cmd_pub.jl:86-157"""

@@ -6,6 +6,8 @@ tag = sys.argv[1]
 root = "gpurun_out/pmc_%s" % tag
 spec = {"headline": ("kmpc_solve_fast_kernel<double,20>", "%kmpc_solve_fast_kernel<double, 20>%", 4096, 64, "python3 bench.py --quick --steps 8 --warmup 4 --no-cpu-baseline"),
         "config3": ("kmpc_solve_fast_kernel<float,20>", "%kmpc_solve_fast_kernel<float, 20>%", 262144, 64, "python3 tools/launch_config.py --horizon 20 --dtype f32 --batch 262144 --cfg 3 --steps 3"),
+        "config3_packed": ("kmpc_solve_fast_kernel<float,20> packed records", "%kmpc_solve_fast_kernel<float, 20>%", 262144, 64, "python3 tools/launch_config.py --horizon 20 --dtype f32 --batch 262144 --cfg 3 --steps 3 --packed"),
+        "headline_packed": ("kmpc_solve_fast_kernel<double,20> packed records", "%kmpc_solve_fast_kernel<double, 20>%", 4096, 64, "python3 tools/launch_config.py --horizon 20 --dtype f64 --batch 4096 --cfg 2 --steps 8 --packed"),
         "config5": ("kmpc_solve_wide_kernel<double,50>", "%kmpc_solve_wide_kernel<double, 50>%", 4096, 256, "python3 tools/launch_config.py --horizon 50 --dtype f64 --batch 4096 --cfg 5 --steps 3")}
 out = {"note": "rocprofv3 --pmc passes (separate runs per counter group, no tracing), averaged over the dispatches of the named kernel at the named grid; "
                "SQ_* summed over the chip per dispatch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)",
