@@ -13,6 +13,10 @@ import numpy as np
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 LAUNCH = dict(path="path3_decimated.npz", track_with_time=True, target_vel=1.0, X0=0.0, Y0=3.0, Psi0=-1.5)   # launch/sim_path_follow.launch:8,9,13,23-25
+# the launch file's two sets of initial conditions with the paths it names for them (:22-30): "Good for Path 1/3" and, commented out, "Good for Path 2, RFS Gate"
+# (X0 = 142, Y0 = -82, Psi0 = 2.0: 8 m and 0.6 rad off path2's first point).  t_settle: seconds after which the cross-track error must stay below 0.5 m.
+VARIANTS = {"path3": dict(LAUNCH, t_settle=10.0, t_peak=0.3), "path1": dict(LAUNCH, path="path1_decimated.npz", t_settle=10.0, t_peak=0.3),
+            "path2": dict(LAUNCH, path="path2_decimated.npz", X0=142.0, Y0=-82.0, Psi0=2.0, t_settle=15.0, t_peak=None)}
 WEIGHTS = (9.0, 9.0, 10.0, 0.0, 100.0, 1000.0, 0.0, 0.0)                                                       # mpc_cmd_pub.jl:49
 
 

@@ -19,32 +19,46 @@ import scenario as S
 STEPS = 720   # 72 s: the stop flag latches after 66.2 s, the car stands ~1 s later
 
 
-def _assert_follows(traj, state, cmd, stop, status, what, overshoot=0.05):
+def _assert_follows(traj, state, cmd, stop, status, what, overshoot=0.05, t_settle=10.0, t_peak=0.3):
     sm = S.summarize(traj, state, cmd, stop)
     nl = sm["n_live"]
     assert nl >= 600 and (np.asarray(status)[:nl] == 0).all(), (what, np.bincount(np.asarray(status)[:nl]))
-    assert sm["ect"][100:nl].max() < 0.5 and sm["ect"][:nl].max() < sm["ect"][0] + overshoot, (what, sm["ect"][100:nl].max(), sm["ect"][:nl].max())
-    if overshoot <= 0.05:   # the launch file's own vehicle: measured 0.226 m after 5 s (a vehicle started 2 m / 0.5 rad off needs up to 8 s to come within 0.5 m)
-        assert sm["ect"][50:nl].max() < 0.3, (what, sm["ect"][50:nl].max())
+    k0 = int(round(t_settle / 0.1))
+    assert sm["ect"][k0:nl].max() < 0.5 and sm["ect"][:nl].max() < sm["ect"][0] + overshoot, (what, sm["ect"][k0:nl].max(), sm["ect"][:nl].max())
+    if overshoot <= 0.05 and t_peak:   # the launch file's own vehicle: measured 0.226 m after 5 s (a vehicle started 2 m / 0.5 rad off needs up to 8 s to come within 0.5 m)
+        assert sm["ect"][50:nl].max() < t_peak, (what, sm["ect"][50:nl].max())
     assert sm["max_dacc"] <= 0.15 + 1.5e-8 and sm["max_ddf"] <= 0.05 + 1.5e-8, (what, sm["max_dacc"], sm["max_ddf"])
     assert np.abs(cmd[:nl, 0]).max() <= 1.0 + 1.5e-8 and np.abs(cmd[:nl, 1]).max() <= 0.5 + 1.5e-8
     assert sm["t_stop"] is not None and 60.0 < sm["t_stop"] < 70.0 and np.asarray(stop)[nl:].all(), (what, sm["t_stop"])
     assert (cmd[nl:] == np.array([-1.0, 0.0])).all()
-    assert state[-1, 3] == 0.0 and np.hypot(*(state[-1, 0:2] - traj[-1, 4:6])) < 3.0, (what, state[-1])  # at rest, within a braking distance of the path's end
+    assert state[-1, 3] == 0.0 and np.hypot(*(state[-1, 0:2] - traj[-1, 4:6])) < 6.0, (what, state[-1])  # at rest, within a braking distance of the end (path1 ends at 3.1 m/s: v^2 / 2 = 4.8 m)
     return sm
 
 
-def test_launch_scenario_cpu_oracle(oracle):
-    """the loop from the oracle's restatements alone (numpy waypoints + numpy plant + C port of the solver): the scenario's expected behaviour, independent of the GPU"""
-    r = S.oracle_closed_loop(oracle, STEPS)
-    sm = _assert_follows(r["traj"], r["state"], r["cmd"], r["stop"], r["status"], "oracle")
+def _oracle_run(oracle, name):
+    V = S.VARIANTS[name]
+    return S.oracle_closed_loop(oracle, STEPS, path=V["path"], X0=V["X0"], Y0=V["Y0"], Psi0=V["Psi0"], target_vel=V["target_vel"], track_with_time=V["track_with_time"])
+
+
+@pytest.mark.parametrize("name", ["path3", "path1", "path2"])
+def test_launch_scenario_cpu_oracle(oracle, name):
+    """the loop from the oracle's restatements alone (numpy waypoints + numpy plant + C port of the solver): the scenario's expected behaviour, independent of the
+    GPU.  path3 is the launch file as it stands; path1 the other path it names for the same start; path2 its commented-out second set (8 m off the path)."""
+    V = S.VARIANTS[name]
+    r = _oracle_run(oracle, name)
+    sm = _assert_follows(r["traj"], r["state"], r["cmd"], r["stop"], r["status"], "oracle " + name, overshoot=0.05 if name != "path2" else 0.3,
+                         t_settle=V["t_settle"], t_peak=V["t_peak"])
     nl = sm["n_live"]
-    assert r["iters"][:nl].mean() < 6.0 and r["iters"][:nl].max() <= 20      # measured 4.86 / 14: warm starts
+    assert r["iters"][:nl].mean() < 6.0 and r["iters"][:nl].max() <= 20      # measured 4.86 / 14 (path3), 4.85 / 15 (path1), 5.43 / 18 (path2): warm starts
     v = r["state"][:nl, 3]
-    assert v.max() > 9.0 and v[300:400].mean() > 8.0                          # it tracks the recorded SPEED profile (time mode), not target_vel = 1.0
-    # the Q8 event is in the run: a waypoint heading far off its neighbours while the recorded heading wraps
+    assert v.max() > 9.0 and v[300:400].mean() > 7.0                          # it tracks the recorded SPEED profile (time mode), not target_vel = 1.0
+    # quirk Q8 in the run: a waypoint heading far off its neighbours while the recorded heading wraps through +-pi (path3: 4 control periods from step 439; path2: 4
+    # from step 592; path1's wrap falls between the sampled waypoints)
     jumps = [k for k in range(nl) if np.abs(np.diff(r["ref"][k][:, 2])).max() > 1.0]
-    assert 1 <= len(jumps) <= 12 and 400 < jumps[0] < 480, jumps
+    if name == "path3":
+        assert 1 <= len(jumps) <= 12 and 400 < jumps[0] < 480, jumps
+    if name == "path2":
+        assert 1 <= len(jumps) <= 12, jumps
 
 
 @pytest.mark.gpu
@@ -91,3 +105,33 @@ def test_launch_scenario_gpu_matches_the_oracle_loop(oracle):
     assert int((~stop[:, 0]).sum()) == n                                                     # both latch the stop flag in the same control period
     assert np.hypot(st[:n + 1, 0, 0] - ro["state"][:n + 1, 0], st[:n + 1, 0, 1] - ro["state"][:n + 1, 1]).max() <= 1e-6
     assert np.abs(st[:n + 1, 0, 2:] - ro["state"][:n + 1, 2:]).max() <= 1e-6 and np.abs(cmd[:n, 0] - ro["cmd"][:n]).max() <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["path1", "path2"])
+def test_other_launch_variants_gpu_match_the_oracle_loop(oracle, name):
+    """the launch file's other path / initial-condition pairs (tests/scenario.py VARIANTS), one vehicle each: the GPU's ClosedLoop reproduces the oracle loop's state
+    history, every solve Optimal, the stop flag latches in the same control period"""
+    import torch
+    from mkz_mpc_path_follower_amd.ref_traj import GPSRefTrajectory
+    from mkz_mpc_path_follower_amd.vehicle_sim import VehicleSimulator
+    from mkz_mpc_path_follower_amd.closed_loop import ClosedLoop
+    V = S.VARIANTS[name]
+    arr, lat0, lon0 = S.path_arrays(V["path"])
+    grt = GPSRefTrajectory(arrays=arr, traj_horizon=8, traj_dt=0.2, lat0=lat0, lon0=lon0)
+    sim = VehicleSimulator(1, X0=V["X0"], Y0=V["Y0"], Psi0=V["Psi0"])
+    loop = ClosedLoop(grt, sim, N=8, target_vel=V["target_vel"], track_with_time=True)
+    st, cmd, status, stop = [sim.state.cpu().numpy().copy()], [], [], []
+    for k in range(STEPS):
+        o = loop.step()
+        torch.cuda.synchronize()
+        stop.append(loop.command_stop.cpu().numpy().copy()); cmd.append(o["cmd"].cpu().numpy().copy()); status.append(o["status"].cpu().numpy().copy())
+        st.append(sim.state.cpu().numpy().copy())
+    st, cmd, status, stop = map(np.array, (st, cmd, status, stop))
+    _assert_follows(grt.get_global_trajectory_reference(), st[:, 0], cmd[:, 0], stop[:, 0], status[:, 0], name, overshoot=0.05 if name != "path2" else 0.3,
+                    t_settle=V["t_settle"], t_peak=V["t_peak"])
+    ro = _oracle_run(oracle, name)
+    n = int((~ro["stop"]).sum())
+    assert int((~stop[:, 0]).sum()) == n
+    assert np.hypot(st[:n + 1, 0, 0] - ro["state"][:n + 1, 0], st[:n + 1, 0, 1] - ro["state"][:n + 1, 1]).max() <= 1e-6
+    assert np.abs(cmd[:n, 0] - ro["cmd"][:n]).max() <= 1e-6
