@@ -435,6 +435,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="skip the multi-seed and other-config extra keys")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank control flow on a one-GPU box)")
+    ap.add_argument("--clock-ramp", type=int, default=100, help="untimed launches BEFORE the W warm-up steps that bring the GPU's clocks up from idle (0 = none)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the asynchronous RCCL all-gather of the N > 1 loop also at --gpus 1 (1-rank nccl group): prices the collective's overhead on one GPU "
                          "and puts the RCCL path under test before multi-GPU hardware shows up (tests/test_bench_cli.py)")
@@ -503,6 +504,13 @@ def main():
     # (host-side set-up of the timed loop comes BEFORE the warm-up, so that nothing but the synchronisation sits between the last warm-up launch and t0)
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(a.steps)]
     wait_host = 0.0
+    # The GPU has idled (and clocked down) while the host generated the inputs: bring it to its sustained state before the W warm-up steps with
+    # untimed launches of the same solve into scratch outputs (reported as config.clock_ramp_launches; --clock-ramp 0 turns it off).  With W = 5 and
+    # nothing else, the first timed kernels ran 3 % slower than the same kernels 30 ms later (0.478 vs 0.461 ms).
+    ramp_out = None
+    for i in range(a.clock_ramp):
+        dj = dins[i % K]
+        ramp_out = solver.solve(dj["z0"], dj["ref"], dj["v_target"], dj["u_prev"], out=ramp_out)
     for i in range(a.warmup):
         s = i % K
         gather.wait(s)
@@ -600,7 +608,7 @@ def main():
             "config": {"workload": cfg_label + "; every rank cycles through the same %d seeded draws (rank r solves draw (step + r) %% %d)" % (K, K),
                        "batch_per_gpu": Bl, "global_batch": B, "horizon": N, "parallelism": "shard%d" % world, "draws": K,
                        "draw_seeds": [20180620 + 2 + 7919 * j for j in range(K)], "kernel_ms_per_draw": per_draw_ms,
-                       "mean_iterations": iters, "optimal_fraction": n_opt / n_tot,
+                       "mean_iterations": iters, "optimal_fraction": n_opt / n_tot, "clock_ramp_launches": a.clock_ramp,
                        "collective": ("none (one rank)" if (world == 1 and not forced) else
                                       "%s all_gather_into_tensor(async_op=True) of the [%d, 2] (accel, steer) block per step, %d slots%s"
                                       % ("RCCL" if a.backend == "nccl" else "gloo", Bl, K, ", forced in a 1-rank group" if forced else "")),
