@@ -203,6 +203,24 @@ def test_golden_fixture_parity(N):
     assert np.abs(r["u0"] - G["U_ipopt_like"][:, 0, :]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("kv,rep", [(0, 1), (1, 1), (0, 32)])
+def test_scenario_fixture_parity(kv, rep):
+    """HIP path vs tests/golden/kmpc_scenario_N8.npz: 36 problems the closed loop meets on the reference's OWN launch scenario (path3, time mode, from rest: standing
+    start, transient, steady tracking, the quirk-Q8 garbage-heading periods, bunched waypoints at the path's end) -- not synthetic arcs -- each solved cold by the
+    full-space Ipopt restatement, the condensed port and scipy.  One-wave kernel, generic kernel, and (rep = 32: 1152 problems) the four-per-wave kernel."""
+    G = np.load(__import__("os").path.join(GOLD, "kmpc_scenario_N8.npz"))
+    d = {k: np.tile(G[k], (rep,) + (1,) * (G[k].ndim - 1)) for k in ("z0", "ref", "v_target", "u_prev")}
+    r = _solve(8, d, weights=tuple(G["weights"]), kernel_variant=kv)
+    assert (r["status"] == 0).all()
+    Jg = np.tile(G["J_ipopt_like"], rep)
+    assert (np.abs(r["cost"] - Jg) <= 1e-6 * np.maximum(1.0, np.abs(Jg))).all()
+    assert r["viol"].max() <= 1e-8 + 1e-12
+    assert np.abs(r["u0"] - np.tile(G["U_condensed"][:, 0, :], (rep, 1))).max() <= 1e-6
+    assert np.abs(r["u0"] - np.tile(G["U_ipopt_like"][:, 0, :], (rep, 1))).max() <= 1e-4
+    r32 = _solve(8, {k: v.astype(np.float32) for k, v in d.items()}, dtype=torch.float32, weights=tuple(G["weights"]), kernel_variant=kv)
+    assert (r32["status"] == 0).all() and (np.abs(r32["cost"] - Jg) <= 1e-3 * np.maximum(1.0, np.abs(Jg))).all() and r32["viol"].max() <= 1e-4
+
+
 def test_full_size_batch_properties():
     """BASELINE configs[1] at full size (B=4096, N=20, fp64): size-independent properties --
     every problem Optimal and feasible, and the mirrored batch (y, psi, steer negated) has the

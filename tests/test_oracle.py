@@ -262,3 +262,19 @@ def test_wrong_point_warm_start_with_a_tiny_barrier_does_not_crawl(oracle, monke
     monkeypatch.setenv("KMPC_X_UNSTICK", "0")
     r0 = O.solve_condensed_batch(*args, o=o, U0=ra["U"].reshape(1, -1), nthreads=1)
     assert r0["status"][0] == 1 and r0["iters"][0] == o.max_iter, (r0["status"], r0["iters"])
+
+
+def test_scenario_fixture_is_what_the_oracle_computes(oracle):
+    """tests/golden/kmpc_scenario_N8.npz (oracle/make_scenario_fixture.py): 36 MPC problems met by the closed loop on the reference's own launch scenario (standing
+    start, transient, steady tracking, the Q8 garbage-heading periods, the bunched waypoints at the path's end), each solved cold by the full-space Ipopt
+    restatement, the condensed port and scipy (agreement 2e-7): the port reproduces its stored answers and the three stored costs agree"""
+    O = oracle
+    G = np.load(os.path.join(GOLD, "kmpc_scenario_N8.npz"))
+    assert len(G["J_ipopt_like"]) >= 36 and any("step_439" in n for n in G["names"]) and any("step_0" == n[-6:] for n in G["names"])
+    p = O.params(8, G["weights"])
+    r = O.solve_condensed_batch(p, G["z0"], G["ref"], G["v_target"], G["u_prev"], nthreads=4)
+    assert (r["status"] == 0).all()
+    scale = np.maximum(1.0, np.abs(G["J_ipopt_like"]))
+    assert (np.abs(r["cost"] - G["J_condensed"]) / scale).max() <= 1e-9
+    assert (np.abs(G["J_condensed"] - G["J_ipopt_like"]) / scale).max() < 2e-7 and (np.abs(G["J_scipy"] - G["J_ipopt_like"]) / scale).max() < 2e-7
+    assert np.abs(r["U"][:, 0, :] - G["U_ipopt_like"][:, 0, :]).max() <= 1e-4      # the published command
