@@ -27,6 +27,8 @@ s_d = max(100, |lam|_1 / m) / 100.  Two scalings are reported, both computed fro
                 MKZMPCPathFollower.jl:65-72; Q9), 1 / max(1, |grad J(0)|_inf / 100) -- the scale on which the reference's
                 `tol = 1e-8` is stated.
 """
+import os
+
 import numpy as np
 from scipy.optimize import nnls
 
@@ -107,9 +109,46 @@ def certify_problem(O, p, q, U, relax=1e-8):
 KEYS = ("scaled_stationarity", "scaled_complementarity", "ref_scaled_stationarity", "ref_scaled_complementarity", "stationarity", "violation", "lam_min", "complementarity", "cost", "threshold")
 
 
+_POOL = None
+
+
+def _pool():
+    """worker processes for large certification jobs (spawned, never forked: the test process may hold a GPU context; the workers touch only numpy and oracle/)"""
+    global _POOL
+    if _POOL is None:
+        import atexit
+        import multiprocessing as mp
+        n = int(os.environ.get("KMPC_CERT_WORKERS", min(8, os.cpu_count() or 1)))
+        keep = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+        os.environ.update({k: "1" for k in keep})  # one BLAS thread per worker (inherited at spawn)
+        _POOL = mp.get_context("spawn").Pool(n) if n > 1 else False
+        for k, v in keep.items():
+            os.environ.pop(k) if v is None else os.environ.__setitem__(k, v)
+        if _POOL:
+            atexit.register(_POOL.terminate)
+    return _POOL
+
+
+def _certify_chunk(a):
+    N, weights, model, z0, ref, vt, up, U, kw = a
+    from oracle import oracle as O
+    p = O.params(N, weights, model=model)
+    rows = []
+    for i in range(len(U)):
+        c = certify_one(O, p, z0[i], ref[i], vt[i], up[i], U[i], **kw)
+        rows.append([c[k] for k in KEYS])
+    return rows
+
+
 def certify_batch(O, p, d, U, idx=None, **kw):
-    """-> dict of arrays over the certified problems (idx = indices into the batch, default all)"""
+    """-> dict of arrays over the certified problems (idx = indices into the batch, default all); jobs of 256 problems and more are spread over worker processes"""
     idx = np.arange(len(U)) if idx is None else np.asarray(idx)
+    pool = _pool() if len(idx) >= 256 else None
+    if pool:
+        chunks = np.array_split(idx, max(1, min(len(idx) // 16, 8 * pool._processes)))
+        args = [(int(p.N), [float(p.C[i]) for i in range(8)], int(p.model), d["z0"][c], d["ref"][c], d["v_target"][c], d["u_prev"][c], np.asarray(U)[c], kw) for c in chunks if len(c)]
+        rows = [r for part in pool.map(_certify_chunk, args) for r in part]
+        return {k: np.array([r[j] for r in rows]) for j, k in enumerate(KEYS)}
     out = {k: [] for k in KEYS}
     for i in idx:
         c = certify_one(O, p, d["z0"][i], d["ref"][i], d["v_target"][i], d["u_prev"][i], U[i], **kw)
