@@ -28,6 +28,7 @@ s_d = max(100, |lam|_1 / m) / 100.  Two scalings are reported, both computed fro
                 `tol = 1e-8` is stated.
 """
 import os
+import sys
 
 import numpy as np
 from scipy.optimize import nnls
@@ -121,7 +122,17 @@ def _pool():
         n = int(os.environ.get("KMPC_CERT_WORKERS", min(8, os.cpu_count() or 1)))
         keep = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
         os.environ.update({k: "1" for k in keep})  # one BLAS thread per worker (inherited at spawn)
-        _POOL = mp.get_context("spawn").Pool(n) if n > 1 else False
+        # the workers import THIS module by name; they must not re-run the parent's main script (a spawned child re-imports `__main__` from its file: an
+        # unguarded tool script would repeat its GPU work in every worker -- the GPU box allows six processes on the card), so the file is hidden meanwhile
+        main = sys.modules.get("__main__")
+        hidden = {a: getattr(main, a) for a in ("__file__", "__spec__") if getattr(main, a, None) is not None}
+        for a in hidden:
+            setattr(main, a, None)
+        try:
+            _POOL = mp.get_context("spawn").Pool(n) if n > 1 else False
+        finally:
+            for a, v in hidden.items():
+                setattr(main, a, v)
         for k, v in keep.items():
             os.environ.pop(k) if v is None else os.environ.__setitem__(k, v)
         if _POOL:

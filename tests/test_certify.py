@@ -372,6 +372,7 @@ def _certify_frenet(O, N, z0, kp, vt, up, U, idx, relax=1e-8):
     ("quad<float>", 8, 1024, True, {}), ("dense<float,12>", 12, 2560, True, {}), ("dense<float,8>", 8, 2560, True, dict(kernel_variant=2)),
     ("dense<double,8>", 8, 2560, False, dict(kernel_variant=2)),
     ("frenet<double,24>", 24, 512, False, dict(model=1)), ("frenet<float,16>", 16, 512, True, dict(model=1)), ("frenet<float,20>", 20, 512, True, dict(model=1)),
+    ("fast<float,16>", 16, 512, True, {}), ("fast<float,20>", 20, 512, True, {}),   # (8 / 16 B of scratch since the fp32 rounding-floor rule of round 4)
 ])
 def test_certify_instantiations_with_scratch(oracle, what, N, B, f32, kw):
     """after round 3's spill / exec-mask hazard "all Optimal by the kernel's own measure" is not evidence for a kernel that spills.

