@@ -559,6 +559,26 @@ def test_out_of_distribution_batch_and_the_fp32_rounding_floor(oracle, N, floor_
             assert np.maximum(c["ref_scaled_stationarity"], c["ref_scaled_complementarity"]).max() <= 1e-2, c   # (the stop on the last iterate: 2.6e-2)
 
 
+def test_out_of_distribution_batch_long_horizon():
+    """The same sweep on the four-wave kernel (N = 50, 65 536 problems; profiles/r4_ood_sweep_N50.txt): cars at 18 - 20 m/s on 10-second references of <= 11 m/s are
+    beyond what 200 iterations solve -- six (fp64) / eight (fp32) problems end as IterationLimit, which is what the reference's max_cpu_time reports as
+    :UserLimit, and the CPU port needs 49 - 189 iterations on them or reaches the cap too.  Asserted: no Error, >= 99.98 % Optimal, and every command inside its box
+    whatever the status (the caller publishes it regardless, mpc_cmd_pub.jl:120-140)."""
+    import os
+    from mkz_mpc_path_follower_amd import BatchMPC
+    from mkz_mpc_path_follower_amd.synthetic import make_ood_batch
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    paths = [dict(np.load(os.path.join(gold, "path%d_decimated.npz" % k))) for k in (1, 2, 3)]
+    d = make_ood_batch(65536, 50, seed=4150, paths=paths)
+    for tdt in (torch.float64, torch.float32):
+        o = BatchMPC(N=50, dtype=tdt).solve(d["z0"], d["ref"], d["v_target"], d["u_prev"])
+        torch.cuda.synchronize()
+        st, u0 = o["status"].cpu().numpy(), o["u0"].cpu().numpy()
+        assert ((st == 0) | (st == 1)).all(), np.bincount(st, minlength=4)
+        assert (st == 0).mean() >= 0.9998, np.bincount(st, minlength=4)
+        assert np.isfinite(u0).all() and (np.abs(u0[:, 0]) <= 1.0 + 1e-4).all() and (np.abs(u0[:, 1]) <= 0.5 + 1e-4).all()
+
+
 def test_slack_guard_trips_on_a_corrupted_slack():
     """The run-time guard of ipm::solve (round 4; VERDICT r3 item 1): round 3 met register-allocator spill code inside a divergent region that handed
     masked-off lanes stale slot contents -- slack iterates drifted from b - a_f^T U and the solver reported a non-KKT point Optimal.  The TEST build

@@ -1,4 +1,4 @@
-"""per-iteration record of one problem of the out-of-distribution batch on the GPU (needs `make -C mkz_mpc_path_follower_amd/csrc trace`); usage: trace_ood.py N index"""
+"""per-iteration record of one problem of the out-of-distribution batch on the GPU (needs `make -C mkz_mpc_path_follower_amd/csrc trace`); usage: trace_ood.py N index [f32|f64] [B of the sweep, default 262144]"""
 import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ from mkz_mpc_path_follower_amd.synthetic import make_ood_batch
 N, b = int(sys.argv[1]), int(sys.argv[2])
 F32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
 paths = [dict(np.load(os.path.join(ROOT, "tests", "golden", "path%d_decimated.npz" % k))) for k in (1, 2, 3)]
-d = make_ood_batch(262144, N, seed=4100 + N, paths=paths)
+d = make_ood_batch(int(sys.argv[4]) if len(sys.argv) > 4 else 262144, N, seed=4100 + N, paths=paths)
 s = BatchMPC(N=N, dtype=torch.float32 if F32 else torch.float64)
 L = _lib.load()
 tr = torch.zeros((256, 8), dtype=torch.float64, device="cuda")
