@@ -7,7 +7,7 @@
 # The program sits directly after `rocprofv3 ... --`.  Digest: gpurun_out/pmc_<tag>/counters.json  ->  profiles/<tag>_pmc_counters.json
 set -eo pipefail
 export TMPDIR=/tmp
-TAG=${1:-r4_v2}
+TAG=${1:-r4_v3}
 OUT=gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 SQA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU"
 SQB="SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"

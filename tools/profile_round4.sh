@@ -5,7 +5,7 @@
 #   2. counter passes of the three priced kernels (tools/pmc_configs.sh): FETCH_SIZE, WRITE_SIZE, two SQ groups
 set -eo pipefail
 export TMPDIR=/tmp
-TAG=${1:-r4_v2}
+TAG=${1:-r4_v3}
 OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 python3 bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 echo "bench done"; tail -c 300 $OUT/bench_plain.json
