@@ -42,3 +42,7 @@ for b in order:
     nfac = c[b, 12] / max(c[order, 12].min() / 1.0, 1.0)
     print("  b=%4d iters %3d cycles %.0f (%.1fx mean)  hard=%s  condense share %.0f%%  sweep1 %.0f cyc/iter" % (b, it[b], tot[b], tot[b] / tot.mean(), d["hard"][b], 100 * c[b, 3] / tot[b], c[b, 12] / it[b]))
 print("iters histogram:", np.bincount(it)[:40])
+b = order[0]
+print("phase cycles per iteration of the slowest problem (b=%d, %d iterations) next to the batch mean:" % (b, it[b]))
+for i, nm in enumerate(NAMES):
+    print("   %-12s %9.0f   %9.0f" % (nm, c[b, i] / it[b], (c[:, i] / it).mean()))
