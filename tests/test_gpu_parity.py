@@ -561,7 +561,7 @@ def test_out_of_distribution_batch_and_the_fp32_rounding_floor(oracle, N, floor_
 
 def test_out_of_distribution_batch_long_horizon():
     """The same sweep on the four-wave kernel (N = 50, 65 536 problems; profiles/r4_ood_sweep_N50.txt): cars at 18 - 20 m/s on 10-second references of <= 11 m/s are
-    beyond what 200 iterations solve -- six (fp64) / eight (fp32) problems end as IterationLimit, which is what the reference's max_cpu_time reports as
+    beyond what 200 iterations solve -- six (fp64) / two (fp32; eight before the rounding-floor rule) problems end as IterationLimit, which is what the reference's max_cpu_time reports as
     :UserLimit, and the CPU port needs 49 - 189 iterations on them or reaches the cap too.  Asserted: no Error, >= 99.98 % Optimal, and every command inside its box
     whatever the status (the caller publishes it regardless, mpc_cmd_pub.jl:120-140)."""
     import os
