@@ -1,4 +1,4 @@
-"""The reference's own scenario (launch/sim_path_follow.launch: path3, time mode, plant at rest at (0, 3, -1.5)) on the GPU through ClosedLoop, next to the
+"""usage: scenario_probe.py [steps] [horizon].  The reference's own scenario (launch/sim_path_follow.launch: path3, time mode, plant at rest at (0, 3, -1.5)) on the GPU through ClosedLoop, next to the
 CPU oracle's run of the same loop (tests/scenario.py): statuses, iterations, tracking summary, largest difference between the two state histories."""
 import os, sys
 import numpy as np, torch
@@ -10,15 +10,16 @@ from mkz_mpc_path_follower_amd.ref_traj import GPSRefTrajectory
 from mkz_mpc_path_follower_amd.vehicle_sim import VehicleSimulator
 from mkz_mpc_path_follower_amd.closed_loop import ClosedLoop
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 700
+NH = int(sys.argv[2]) if len(sys.argv) > 2 else 8   # horizon (the reference: 8)
 L = S.LAUNCH
 arr, lat0, lon0 = S.path_arrays()
-grt = GPSRefTrajectory(arrays=arr, traj_horizon=8, traj_dt=0.2, lat0=lat0, lon0=lon0)
+grt = GPSRefTrajectory(arrays=arr, traj_horizon=NH, traj_dt=0.2, lat0=lat0, lon0=lon0)
 B = 65
 rng = np.random.default_rng(3)
 X0 = np.concatenate([[L["X0"]], L["X0"] + rng.uniform(-2, 2, B - 1)]); Y0 = np.concatenate([[L["Y0"]], L["Y0"] + rng.uniform(-2, 2, B - 1)])
 P0 = np.concatenate([[L["Psi0"]], L["Psi0"] + rng.uniform(-0.5, 0.5, B - 1)])
 sim = VehicleSimulator(B, X0=X0, Y0=Y0, Psi0=P0)
-loop = ClosedLoop(grt, sim, N=8, target_vel=L["target_vel"], track_with_time=True)
+loop = ClosedLoop(grt, sim, N=NH, target_vel=L["target_vel"], track_with_time=True)
 st, cmd, status, iters, stop = [sim.state.cpu().numpy().copy()], [], [], [], []
 for k in range(steps):
     o = loop.step()
@@ -26,7 +27,7 @@ for k in range(steps):
     stop.append(loop.command_stop.cpu().numpy().copy()); cmd.append(o["cmd"].cpu().numpy().copy()); status.append(o["status"].cpu().numpy().copy())
     iters.append(o["iters"].cpu().numpy().copy()); st.append(sim.state.cpu().numpy().copy())
 st, cmd, status, iters, stop = map(np.array, (st, cmd, status, iters, stop))
-ro = S.oracle_closed_loop(O, steps)
+ro = S.oracle_closed_loop(O, steps, N=NH)
 tr = grt.get_global_trajectory_reference()
 for b in (0, 1, 2, 3):
     sm = S.summarize(tr, st[:, b], cmd[:, b], stop[:, b])
