@@ -1,4 +1,5 @@
-"""oracle/make_scenario_fixture.py -- TEST INFRASTRUCTURE.  Writes tests/golden/kmpc_scenario_N8.npz.  PARITY UNPINNED (see make_golden.py).
+"""oracle/make_scenario_fixture.py -- TEST INFRASTRUCTURE.  Writes tests/golden/kmpc_scenario_N<N>.npz (N = 8, the reference's horizon, by default; committed also for
+N = 20, BASELINE configs[1]'s).  PARITY UNPINNED (see make_golden.py).
 
 Fixture problems from the reference's OWN verification scenario instead of synthetic arcs (every rule of the iteration had been validated on one
 input family): the MPC problems the CPU oracle's closed loop meets on launch/sim_path_follow.launch -- path3, time mode, the plant at rest at (0, 3, -1.5)
@@ -6,7 +7,7 @@ input family): the MPC problems the CPU oracle's closed loop meets on launch/sim
 which quirk Q8 hands the MPC a garbage heading on one waypoint (ref_gps_traj.py:195 interpolates psi before unwrapping), the approach to the path's end where
 the time-mode waypoints bunch up.  Each problem (state, reference window, previous command) is solved COLD by the three independent solvers of make_golden.py
 (full-space Ipopt restatement from its all-zero start, condensed port, scipy trust-constr) and stored only if they agree to 2e-7.
-Run from the repo root:  python oracle/make_scenario_fixture.py"""
+Run from the repo root:  python oracle/make_scenario_fixture.py [N]"""
 import os
 import sys
 
@@ -20,10 +21,11 @@ from oracle import oracle as O  # noqa: E402
 from oracle.make_golden import NODE_WEIGHTS, _solve_three  # noqa: E402
 
 if __name__ == "__main__":
-    N = 8
-    run = S.oracle_closed_loop(O, 700)
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    run = S.oracle_closed_loop(O, 700, N=N)
     nl = int((~run["stop"]).sum())
     steps = sorted(set([0, 1, 2, 3, 5, 8, 12, 20, 30, 50, 80, 120, 160, 200, 250, 300, 350, 400, 430, 438, 439, 440, 445, 446, 451, 452, 453, 454, 460, 470, 500, 550, 600, 640, 650, 655, 658, 660, nl - 1]))
+    steps = [k for k in steps if k < nl]   # (a longer horizon reaches the path's end earlier)
     probs = []
     for k in steps:
         st = run["state"][k]
@@ -41,6 +43,6 @@ if __name__ == "__main__":
                J_ipopt_like=np.array([r["Ji"] for r in rows]), J_condensed=np.array([r["Jc"] for r in rows]), J_scipy=np.array([r["Js"] for r in rows]),
                U_ipopt_like=np.array([r["Ui"] for r in rows]), U_condensed=np.array([r["Uc"] for r in rows]), U_scipy=np.array([r["Us"] for r in rows]),
                X_ipopt_like=np.array([r["Xi"] for r in rows]), excluded=np.array(["%s: %s" % r for r in excluded] or [""]))
-    path = os.path.join(ROOT, "tests", "golden", "kmpc_scenario_N8.npz")
+    path = os.path.join(ROOT, "tests", "golden", "kmpc_scenario_N%d.npz" % N)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(rows), "problems,", len(excluded), "excluded")

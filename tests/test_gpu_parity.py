@@ -203,21 +203,22 @@ def test_golden_fixture_parity(N):
     assert np.abs(r["u0"] - G["U_ipopt_like"][:, 0, :]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("kv,rep", [(0, 1), (1, 1), (0, 32)])
-def test_scenario_fixture_parity(kv, rep):
-    """HIP path vs tests/golden/kmpc_scenario_N8.npz: 36 problems the closed loop meets on the reference's OWN launch scenario (path3, time mode, from rest: standing
-    start, transient, steady tracking, the quirk-Q8 garbage-heading periods, bunched waypoints at the path's end) -- not synthetic arcs -- each solved cold by the
-    full-space Ipopt restatement, the condensed port and scipy.  One-wave kernel, generic kernel, and (rep = 32: 1152 problems) the four-per-wave kernel."""
-    G = np.load(__import__("os").path.join(GOLD, "kmpc_scenario_N8.npz"))
+@pytest.mark.parametrize("N,kv,rep", [(8, 0, 1), (8, 1, 1), (8, 0, 32), (20, 0, 1), (20, 1, 1), (20, 0, 128)])
+def test_scenario_fixture_parity(N, kv, rep):
+    """HIP path vs tests/golden/kmpc_scenario_N{8,20}.npz: 36 / 33 problems the closed loop meets on the reference's OWN launch scenario (path3, time mode, from rest:
+    standing start, transient, steady tracking, the quirk-Q8 garbage-heading periods, bunched waypoints at the path's end) -- not synthetic arcs -- at the reference's
+    horizon and at BASELINE configs[1]'s, each solved cold by the full-space Ipopt restatement, the condensed port and scipy.  One-wave kernel, generic kernel, and
+    (N = 8, rep = 32: 1152 problems) the four-per-wave kernel / (N = 20, rep = 128: 4224 problems) the start-order pre-pass."""
+    G = np.load(__import__("os").path.join(GOLD, "kmpc_scenario_N%d.npz" % N))
     d = {k: np.tile(G[k], (rep,) + (1,) * (G[k].ndim - 1)) for k in ("z0", "ref", "v_target", "u_prev")}
-    r = _solve(8, d, weights=tuple(G["weights"]), kernel_variant=kv)
+    r = _solve(N, d, weights=tuple(G["weights"]), kernel_variant=kv)
     assert (r["status"] == 0).all()
     Jg = np.tile(G["J_ipopt_like"], rep)
     assert (np.abs(r["cost"] - Jg) <= 1e-6 * np.maximum(1.0, np.abs(Jg))).all()
     assert r["viol"].max() <= 1e-8 + 1e-12
     assert np.abs(r["u0"] - np.tile(G["U_condensed"][:, 0, :], (rep, 1))).max() <= 1e-6
     assert np.abs(r["u0"] - np.tile(G["U_ipopt_like"][:, 0, :], (rep, 1))).max() <= 1e-4
-    r32 = _solve(8, {k: v.astype(np.float32) for k, v in d.items()}, dtype=torch.float32, weights=tuple(G["weights"]), kernel_variant=kv)
+    r32 = _solve(N, {k: v.astype(np.float32) for k, v in d.items()}, dtype=torch.float32, weights=tuple(G["weights"]), kernel_variant=kv)
     assert (r32["status"] == 0).all() and (np.abs(r32["cost"] - Jg) <= 1e-3 * np.maximum(1.0, np.abs(Jg))).all() and r32["viol"].max() <= 1e-4
 
 

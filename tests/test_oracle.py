@@ -264,14 +264,16 @@ def test_wrong_point_warm_start_with_a_tiny_barrier_does_not_crawl(oracle, monke
     assert r0["status"][0] == 1 and r0["iters"][0] == o.max_iter, (r0["status"], r0["iters"])
 
 
-def test_scenario_fixture_is_what_the_oracle_computes(oracle):
-    """tests/golden/kmpc_scenario_N8.npz (oracle/make_scenario_fixture.py): 36 MPC problems met by the closed loop on the reference's own launch scenario (standing
-    start, transient, steady tracking, the Q8 garbage-heading periods, the bunched waypoints at the path's end), each solved cold by the full-space Ipopt
-    restatement, the condensed port and scipy (agreement 2e-7): the port reproduces its stored answers and the three stored costs agree"""
+@pytest.mark.parametrize("N,count", [(8, 36), (20, 33)])
+def test_scenario_fixture_is_what_the_oracle_computes(oracle, N, count):
+    """tests/golden/kmpc_scenario_N{8,20}.npz (oracle/make_scenario_fixture.py [N]): 36 / 33 MPC problems met by the closed loop on the reference's own launch scenario
+    (standing start, transient, steady tracking, the Q8 garbage-heading periods, the bunched waypoints at the path's end) at the reference's horizon and at BASELINE
+    configs[1]'s, each solved cold by the full-space Ipopt restatement, the condensed port and scipy (agreement 2e-7): the port reproduces its stored answers and
+    the three stored costs agree"""
     O = oracle
-    G = np.load(os.path.join(GOLD, "kmpc_scenario_N8.npz"))
-    assert len(G["J_ipopt_like"]) >= 36 and any("step_439" in n for n in G["names"]) and any("step_0" == n[-6:] for n in G["names"])
-    p = O.params(8, G["weights"])
+    G = np.load(os.path.join(GOLD, "kmpc_scenario_N%d.npz" % N))
+    assert int(G["N"]) == N and len(G["J_ipopt_like"]) >= count and any("step_439" in n for n in G["names"]) and any("step_0" == n[-6:] for n in G["names"])
+    p = O.params(N, G["weights"])
     r = O.solve_condensed_batch(p, G["z0"], G["ref"], G["v_target"], G["u_prev"], nthreads=4)
     assert (r["status"] == 0).all()
     scale = np.maximum(1.0, np.abs(G["J_ipopt_like"]))
