@@ -1,5 +1,5 @@
 """oracle/make_scenario_fixture.py -- TEST INFRASTRUCTURE.  Writes tests/golden/kmpc_scenario_N<N>.npz (N = 8, the reference's horizon, by default; committed also for
-N = 20, BASELINE configs[1]'s).  PARITY UNPINNED (see make_golden.py).
+N = 20 and N = 50, the horizons of BASELINE configs[1] / configs[4]; N = 50 takes ~25 minutes).  PARITY UNPINNED (see make_golden.py).
 
 Fixture problems from the reference's OWN verification scenario instead of synthetic arcs (every rule of the iteration had been validated on one
 input family): the MPC problems the CPU oracle's closed loop meets on launch/sim_path_follow.launch -- path3, time mode, the plant at rest at (0, 3, -1.5)

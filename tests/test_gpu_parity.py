@@ -203,12 +203,12 @@ def test_golden_fixture_parity(N):
     assert np.abs(r["u0"] - G["U_ipopt_like"][:, 0, :]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("N,kv,rep", [(8, 0, 1), (8, 1, 1), (8, 0, 32), (20, 0, 1), (20, 1, 1), (20, 0, 128)])
+@pytest.mark.parametrize("N,kv,rep", [(8, 0, 1), (8, 1, 1), (8, 0, 32), (20, 0, 1), (20, 1, 1), (20, 0, 128), (50, 0, 1), (50, 1, 1), (50, 0, 128)])
 def test_scenario_fixture_parity(N, kv, rep):
-    """HIP path vs tests/golden/kmpc_scenario_N{8,20}.npz: 36 / 33 problems the closed loop meets on the reference's OWN launch scenario (path3, time mode, from rest:
+    """HIP path vs tests/golden/kmpc_scenario_N{8,20,50}.npz: 36 / 33 / 33 problems the closed loop meets on the reference's OWN launch scenario (path3, time mode, from rest:
     standing start, transient, steady tracking, the quirk-Q8 garbage-heading periods, bunched waypoints at the path's end) -- not synthetic arcs -- at the reference's
-    horizon and at BASELINE configs[1]'s, each solved cold by the full-space Ipopt restatement, the condensed port and scipy.  One-wave kernel, generic kernel, and
-    (N = 8, rep = 32: 1152 problems) the four-per-wave kernel / (N = 20, rep = 128: 4224 problems) the start-order pre-pass."""
+    horizon and at those of BASELINE configs[1] and configs[4], each solved cold by the full-space Ipopt restatement, the condensed port and scipy.  One-wave / four-wave
+    kernel, generic kernel, and (N = 8, rep = 32: 1152 problems) the four-per-wave kernel / (N = 20, 50, rep = 128: 4224 problems) the start-order pre-pass."""
     G = np.load(__import__("os").path.join(GOLD, "kmpc_scenario_N%d.npz" % N))
     d = {k: np.tile(G[k], (rep,) + (1,) * (G[k].ndim - 1)) for k in ("z0", "ref", "v_target", "u_prev")}
     r = _solve(N, d, weights=tuple(G["weights"]), kernel_variant=kv)

@@ -264,11 +264,11 @@ def test_wrong_point_warm_start_with_a_tiny_barrier_does_not_crawl(oracle, monke
     assert r0["status"][0] == 1 and r0["iters"][0] == o.max_iter, (r0["status"], r0["iters"])
 
 
-@pytest.mark.parametrize("N,count", [(8, 36), (20, 33)])
+@pytest.mark.parametrize("N,count", [(8, 36), (20, 33), (50, 33)])
 def test_scenario_fixture_is_what_the_oracle_computes(oracle, N, count):
-    """tests/golden/kmpc_scenario_N{8,20}.npz (oracle/make_scenario_fixture.py [N]): 36 / 33 MPC problems met by the closed loop on the reference's own launch scenario
-    (standing start, transient, steady tracking, the Q8 garbage-heading periods, the bunched waypoints at the path's end) at the reference's horizon and at BASELINE
-    configs[1]'s, each solved cold by the full-space Ipopt restatement, the condensed port and scipy (agreement 2e-7): the port reproduces its stored answers and
+    """tests/golden/kmpc_scenario_N{8,20,50}.npz (oracle/make_scenario_fixture.py [N]): 36 / 33 / 33 MPC problems met by the closed loop on the reference's own launch scenario
+    (standing start, transient, steady tracking, the Q8 garbage-heading periods, the bunched waypoints at the path's end) at the reference's horizon and at those of BASELINE
+    configs[1] and configs[4], each solved cold by the full-space Ipopt restatement, the condensed port and scipy (agreement 2e-7): the port reproduces its stored answers and
     the three stored costs agree"""
     O = oracle
     G = np.load(os.path.join(GOLD, "kmpc_scenario_N%d.npz" % N))
